@@ -1,0 +1,280 @@
+// Flash-style attention for gfx950:  O = softmax(Q K^T * scale) V, bf16 in/out, fp32 softmax + accumulation.
+// Replaces diffusers' Attention processor (F.scaled_dot_product_attention / xformers, pipeline.py:138-142)
+// inside BasicTransformerBlock.attn1 / attn2 as called from flownet.py:87-118 and pipeline.py:358-367.
+//
+// Formulation (per wave: 32 queries; per workgroup: 4 waves = 128 queries sharing the K/V tiles in LDS):
+//   S^T[key][q] = K . Q^T      v_mfma_f32_32x32x16_bf16, A = K rows from LDS, B = Q^T held in registers
+//   -> every lane owns ONE query column (q = lane & 31) and 16 of the 32 keys of the tile in its 16 accumulator
+//      registers: the row max / row sum are lane-local plus one exchange with lane^32, and the probabilities,
+//      converted pairwise to bf16, ARE the B operand of the next MFMA (no LDS round trip):
+//   O^T[d][q]  += V^T . P^T     A = V^T tile (LDS, keys permuted to the accumulator's k order), B = P^T registers
+//   The online-softmax rescale factor is per query = per lane, so it is one scalar multiply on the O accumulators.
+// Head dims that are not multiples of 16/32 (d = 40) are zero-padded in LDS/registers.
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key MFMA tiles)
+constexpr int VT_PITCH = KV_TILE * 2 + 8;    // bytes per V^T row: 136 -> ds_read_b64 conflict-free (17 mod 32 slots)
+
+struct AttnArgs {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;
+    int B, heads, Nq, Nk;
+    long long qs, ks, vs, os;
+    float scale_log2e;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
+{
+    constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
+    constexpr int NDT = (D + 31) / 32;               // 32-row output tiles of O^T
+    constexpr int NV = D / 8;                        // 16-byte vectors per K/V row
+    constexpr int KP16 = (ND16 * 2) | 1;             // K row pitch in 16-B units, odd -> conflict-free ds_read_b128
+    constexpr int K_PITCH = KP16 * 16;
+    constexpr int K_BYTES = KV_TILE * K_PITCH;
+    constexpr int VT_ROWS = NDT * 32;
+    constexpr int VT_BYTES = VT_ROWS * VT_PITCH;
+    constexpr int BUF = K_BYTES + VT_BYTES;
+    constexpr int NLD = (KV_TILE * NV + 255) / 256;  // vectors per thread per operand per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, lh = lane >> 5;
+    const int qblocks = (a.Nq + 127) / 128;
+    const int bh = blockIdx.x / qblocks;
+    const int qb = blockIdx.x - bh * qblocks;
+    const int b = bh / a.heads, h = bh - b * a.heads;
+    const int q0 = qb * 128 + wave * 32;
+
+    const bf16_t* __restrict__ Q = a.q + (long long)b * a.Nq * a.qs + h * D;
+    const bf16_t* __restrict__ K = a.k + (long long)b * a.Nk * a.ks + h * D;
+    const bf16_t* __restrict__ V = a.v + (long long)b * a.Nk * a.vs + h * D;
+
+    // zero both LDS buffers once: pad columns (d >= D) and never-written bytes must be finite zeros
+    for (int i = tid * 16; i < 2 * BUF; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // Q^T fragments: lane holds Q[q0+lq][16*ks + 8*lh .. +7]
+    bf16x8 qf[ND16];
+#pragma unroll
+    for (int ks = 0; ks < ND16; ++ks) {
+        const int dcol = 16 * ks + 8 * lh;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q0 + lq < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)(q0 + lq) * a.qs + dcol);
+        qf[ks] = *(bf16x8*)&v;
+    }
+
+    f32x16 oacc[NDT];
+#pragma unroll
+    for (int t = 0; t < NDT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    u32x4 rk[NLD], rv[NLD];
+    const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
+
+    auto issue_loads = [&](int t) {
+        const int kb = t * KV_TILE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx & 63, vec = idx >> 6;       // consecutive lanes -> consecutive keys
+            u32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (vec < NV && kb + key < a.Nk) {
+                kk = *(const u32x4*)(K + (long long)(kb + key) * a.ks + vec * 8);
+                vv = *(const u32x4*)(V + (long long)(kb + key) * a.vs + vec * 8);
+            }
+            rk[i] = kk;
+            rv[i] = vv;
+        }
+    };
+    auto store_lds = [&](int buf) {
+        char* sK = smem + buf * BUF;
+        char* sV = sK + K_BYTES;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx & 63, vec = idx >> 6;
+            if (vec < NV) {
+                *(u32x4*)(sK + key * K_PITCH + vec * 16) = rk[i];
+                // transposed V: V^T[d][key]
+                const bf16x8 vv = *(bf16x8*)&rv[i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *(bf16_t*)(sV + (vec * 8 + j) * VT_PITCH + key * 2) = vv[j];
+            }
+        }
+    };
+
+    __syncthreads();                  // zero-fill complete before the first tile lands
+    issue_loads(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ntiles;
+        if (more) issue_loads(t + 1);
+        const char* sK = smem + buf * BUF;
+        const char* sV = sK + K_BYTES;
+
+        // ---- S^T tiles (2 x 32 keys)
+        f32x16 s[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < ND16; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (32 * j + lq) * K_PITCH + (16 * ks + 8 * lh) * 2);
+                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (base-2 domain)
+        const int kb = t * KV_TILE;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float x = s[j][r] * a.scale_log2e;
+                if (key >= a.Nk) x = -INFINITY;
+                s[j][r] = x;
+                mloc = fmaxf(mloc, x);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);        // 0 on the first tile (m_run = -inf, m_new finite)
+        m_run = m_new;
+        float lsum = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[j][r] - m_new);
+                lsum += p;
+                pf[j][r >> 3][r & 7] = (bf16_t)p;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt) {
+            const char* vrow = sV + (32 * tt + lq) * VT_PITCH;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int k0 = 32 * j + 16 * s2 + 4 * lh;
+                    const u32x2 lo = *(const u32x2*)(vrow + k0 * 2);
+                    const u32x2 hi = *(const u32x2*)(vrow + (k0 + 8) * 2);
+                    u32x4 av = {lo[0], lo[1], hi[0], hi[1]};
+                    oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[j][s2], oacc[tt], 0, 0, 0);
+                }
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finish: O[q][d] = O^T[d][q] / l
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + lq;
+    if (qi < a.Nq) {
+        bf16_t* __restrict__ O = a.o + ((long long)b * a.Nq + qi) * a.os + h * D;
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dcol = 32 * tt + 8 * g + 4 * lh;
+                if (dcol < D) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(oacc[tt][4 * g + r] * inv);
+                    *(bf16x4*)(O + dcol) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch(const AttnArgs& a, hipStream_t st)
+{
+    constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
+    constexpr int KP16 = (ND16 * 2) | 1;
+    constexpr int BUF = KV_TILE * KP16 * 16 + NDT * 32 * VT_PITCH;
+    const size_t lds = 2 * BUF;
+    auto kern = attn_kernel<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int qblocks = (a.Nq + 127) / 128;
+    hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);
+    return dc_launch_status();
+}
+
+// Row softmax fp32 -> bf16 (one workgroup per row; cols <= 65536).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                            int cols, float scale)
+{
+    __shared__ float red[8];
+    const long long row = blockIdx.x;
+    const float* x = s + row * cols;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < cols; i += 256) m = fmaxf(m, x[i] * scale);
+    m = dc_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) sum += __expf(x[i] * scale - m);
+    sum = dc_wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    bf16_t* o = p + row * cols;
+    for (int i = threadIdx.x; i < cols; i += 256) o[i] = (bf16_t)(__expf(x[i] * scale - m) * inv);
+}
+
+}  // namespace
+
+extern "C" int dc_attention_bf16(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq,
+                                 int Nk, int D, long long q_stride, long long k_stride, long long v_stride,
+                                 long long o_stride, float scale, void* stream)
+{
+    if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DC_ERR_INVALID;
+    if ((q_stride | k_stride | v_stride | o_stride) & 7) return DC_ERR_INVALID;     // 16-byte aligned rows
+    AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, B, heads, Nq, Nk,
+               q_stride, k_stride, v_stride, o_stride, scale * 1.4426950408889634f};
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {
+        case 8: return launch<8>(a, st);
+        case 16: return launch<16>(a, st);
+        case 32: return launch<32>(a, st);
+        case 40: return launch<40>(a, st);
+        case 64: return launch<64>(a, st);
+        case 80: return launch<80>(a, st);
+        case 128: return launch<128>(a, st);
+        case 160: return launch<160>(a, st);
+        default: return DC_ERR_INVALID;
+    }
+}
+
+extern "C" int dc_softmax_rows_f32_to_bf16(const float* s, void* p, long long rows, int cols, float scale, void* stream)
+{
+    if (!s || !p || rows <= 0 || cols <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, cols, scale);
+    return dc_launch_status();
+}

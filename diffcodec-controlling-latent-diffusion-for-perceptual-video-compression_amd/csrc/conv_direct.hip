@@ -1,0 +1,210 @@
+// Direct (non-MFMA) convolutions for the layers that are not GEMM-shaped on gfx950:
+//   * fp32 NCHW 3x3 convs of the control extractors (controlnet/extractors.py:215-262, control_utils.py:43-47):
+//     kept in fp32 like the reference's splat stage (softsplat.py:279); LDS-tiled 16x16 output pixels x 16 couts.
+//   * NHWC bf16 convs with <= 16 input channels (UNet/ControlNet conv_in 4->320, VAE conv_in, post_quant_conv)
+//   * NHWC bf16 convs with <= 8 output channels (UNet conv_out 320->4 with fused GroupNorm+SiLU, VAE conv_out,
+//     quant_conv): one wave per output pixel, lanes split the (tap, channel-vector) reduction.
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+constexpr int CO_T = 16;     // output channels per workgroup
+constexpr int CI_T = 8;      // input channels staged per step
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_nchw_f32_kernel(const float* __restrict__ x, long long xbs,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int Cin, int H, int W, int Cout,
+                                                               int Ho, int Wo, int silu)
+{
+    constexpr int PT = 16 * STRIDE + 2;                 // input patch edge
+    __shared__ float s_in[CI_T][PT][PT + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[CI_T][9][CO_T];
+    const int tiles_x = (Wo + 15) / 16;
+    const int tx0 = (blockIdx.x % tiles_x) * 16, ty0 = (blockIdx.x / tiles_x) * 16;
+    const int co0 = blockIdx.y * CO_T;
+    const int n = blockIdx.z;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int ox = tx0 + lx, oy = ty0 + ly;
+    float acc[CO_T];
+#pragma unroll
+    for (int i = 0; i < CO_T; ++i) acc[i] = 0.f;
+    const int ix0 = tx0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1;
+    for (int c0 = 0; c0 < Cin; c0 += CI_T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CI_T * PT * PT; i += 256) {
+            const int px = i % PT, py = (i / PT) % PT, ci = i / (PT * PT);
+            const int gx = ix0 + px, gy = iy0 + py, c = c0 + ci;
+            float v = 0.f;
+            if (c < Cin && gx >= 0 && gx < W && gy >= 0 && gy < H) v = x[n * xbs + ((long long)c * H + gy) * W + gx];
+            s_in[ci][py][px] = v;
+        }
+        for (int i = threadIdx.x; i < CI_T * 9 * CO_T; i += 256) {
+            const int co = i % CO_T, tap = (i / CO_T) % 9, ci = i / (CO_T * 9);
+            float v = 0.f;
+            if (c0 + ci < Cin && co0 + co < Cout) v = w[(((long long)(co0 + co)) * Cin + (c0 + ci)) * 9 + tap];
+            s_w[ci][tap][co] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < CI_T; ++ci) {
+            float in[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) in[t] = s_in[ci][ly * STRIDE + t / 3][lx * STRIDE + t % 3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int g = 0; g < CO_T / 4; ++g) {
+                    const f32x4 wv = *(const f32x4*)&s_w[ci][t][4 * g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[4 * g + r] += in[t] * wv[r];
+                }
+            }
+        }
+    }
+    if (ox < Wo && oy < Ho) {
+#pragma unroll
+        for (int i = 0; i < CO_T; ++i) {
+            const int co = co0 + i;
+            if (co < Cout) {
+                float v = acc[i] + (bias ? bias[co] : 0.f);
+                if (silu) v = dc_silu(v);
+                y[(((long long)n * Cout + co) * Ho + oy) * Wo + ox] = v;
+            }
+        }
+    }
+}
+
+// thread = (pixel, group of 8 output channels); w [taps][Cin][Cout] bf16
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                             int N, int H, int W, int Cin, int Cout, int ks, int stride,
+                                                             int pad, int Ho, int Wo)
+{
+    const int cog = (Cout + 7) / 8;
+    const long long total = (long long)N * Ho * Wo * cog;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % cog);
+    const long long m = i / cog;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), n = (int)(m / ((long long)Wo * Ho));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const bf16_t* xp = x + (((long long)n * H + iy) * W + ix) * Cin;
+            const bf16_t* wp = w + (long long)(ky * ks + kx) * Cin * Cout + g * 8;
+            for (int c = 0; c < Cin; ++c) {
+                const float xv = (float)xp[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (g * 8 + j < Cout) acc[j] += xv * (float)wp[(long long)c * Cout + j];
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int co = g * 8 + j;
+        if (co < Cout) out[m * Cout + co] = (bf16_t)(acc[j] + (bias ? bias[co] : 0.f));
+    }
+}
+
+// one wave per output pixel; w [Cout][taps][Cin] bf16; stride 1, pad (ks-1)/2
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ ab,
+                                                              int silu, int gn_batch, void* __restrict__ out, int out_f32,
+                                                              int N, int H, int W, int Cin, int ks)
+{
+    const int lane = threadIdx.x & 63;
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long M = (long long)N * H * W;
+    if (m >= M) return;
+    const int ox = (int)(m % W), oy = (int)((m / W) % H), n = (int)(m / ((long long)W * H));
+    const int nv = Cin >> 3, taps = ks * ks, padk = (ks - 1) / 2;
+    float acc[COUT];
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) acc[j] = 0.f;
+    for (int idx = lane; idx < taps * nv; idx += 64) {
+        const int tap = idx / nv, v = idx - tap * nv;
+        const int iy = oy + tap / ks - padk, ix = ox + tap % ks - padk;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const bf16x8 xv = *(const bf16x8*)(x + (((long long)n * H + iy) * W + ix) * Cin + v * 8);
+        float xf[8];
+        if (ab) {
+            const float* abp = ab + ((long long)(n % gn_batch) * Cin + v * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = (float)xv[j] * abp[2 * j] + abp[2 * j + 1];
+                xf[j] = silu ? dc_silu(t) : t;
+                xf[j] = (float)(bf16_t)xf[j];          // same rounding point as the MFMA path (bf16 operand)
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = (float)xv[j];
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const bf16x8 wv = *(const bf16x8*)(w + ((long long)co * taps + tap) * Cin + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[co] += xf[j] * (float)wv[j];
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = dc_wave_sum(acc[co]);
+    if (lane == 0) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float v = acc[co] + (bias ? bias[co] : 0.f);
+            if (out_f32) ((float*)out)[m * COUT + co] = v;
+            else ((bf16_t*)out)[m * COUT + co] = (bf16_t)v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, const float* w, const float* bias, float* y,
+                                   int N, int Cin, int H, int W, int Cout, int stride, int silu, void* stream)
+{
+    if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return DC_ERR_INVALID;
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const dim3 grid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, CO_T), N);
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) hipLaunchKernelGGL(conv3x3_nchw_f32_kernel<1>, grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+    else hipLaunchKernelGGL(conv3x3_nchw_f32_kernel<2>, grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+    return dc_launch_status();
+}
+
+extern "C" int dc_conv_small_cin_bf16(const void* x, const void* w, const float* bias, void* out, int N, int H, int W,
+                                      int Cin, int Cout, int ksize, int stride, int pad, int Ho, int Wo, void* stream)
+{
+    if (!x || !w || !out || N <= 0 || Cin <= 0 || Cin > 16 || Cout <= 0 || (ksize != 1 && ksize != 3)) return DC_ERR_INVALID;
+    const long long total = (long long)N * Ho * Wo * ((Cout + 7) / 8);
+    hipLaunchKernelGGL(conv_small_cin_kernel, dim3(dc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)w, bias, (bf16_t*)out, N, H, W, Cin, Cout, ksize, stride, pad, Ho, Wo);
+    return dc_launch_status();
+}
+
+extern "C" int dc_conv_small_cout_bf16(const void* x, const void* w, const float* bias, const float* gn_ab, int gn_silu,
+                                       int gn_batch, void* out, int out_f32, int N, int H, int W, int Cin, int Cout,
+                                       int ksize, void* stream)
+{
+    if (!x || !w || !out || N <= 0 || Cin <= 0 || (Cin & 7) || (ksize != 1 && ksize != 3)) return DC_ERR_INVALID;
+    if (gn_ab && gn_batch <= 0) return DC_ERR_INVALID;
+    const long long M = (long long)N * H * W;
+    const dim3 grid(dc_cdiv(M, 4));
+    hipStream_t st = (hipStream_t)stream;
+#define DC_SC(CO) hipLaunchKernelGGL(conv_small_cout_kernel<CO>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w, bias, gn_ab, gn_silu, gn_batch, out, out_f32, N, H, W, Cin, ksize)
+    switch (Cout) {
+        case 3: DC_SC(3); break;
+        case 4: DC_SC(4); break;
+        case 8: DC_SC(8); break;
+        default: return DC_ERR_INVALID;
+    }
+#undef DC_SC
+    return dc_launch_status();
+}

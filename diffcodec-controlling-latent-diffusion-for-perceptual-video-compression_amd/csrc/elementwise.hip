@@ -1,0 +1,225 @@
+// Layout / dtype / scheduler elementwise kernels (HBM-bound) for gfx950.
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+inline int grid_for(long long total) { return (int)min((long long)8192, (total + 255) / 256); }
+
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, int C, long long HW, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = (i / C) % HW, n = i / (C * HW);
+        d[i] = (bf16_t)s[(n * C + c) * HW + p];
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ s, float* __restrict__ d, int C, long long HW, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long long n = i / (C * HW);
+        d[i] = (float)s[(n * HW + p) * C + c];
+    }
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = (bf16_t)s[i];
+}
+__global__ void silu_f32_kernel(const float* __restrict__ s, float* __restrict__ d, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = dc_silu(s[i]);
+}
+__global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long long nvec)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const bf16x8 av = *(const bf16x8*)(a + i * 8), bv = *(const bf16x8*)(b + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)av[j] + (float)bv[j]);
+        *(bf16x8*)(y + i * 8) = o;
+    }
+}
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, const int* __restrict__ step, float* __restrict__ out, int n, int dim)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= n * half) return;
+    const int k = i % half, r = i / half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+    const float a = t[step ? *step : 0] * freq;
+    out[(long long)r * dim + k] = cosf(a);
+    out[(long long)r * dim + half + k] = sinf(a);
+}
+// pipeline.py:370-375: CFG combine, DDIM update (fp32 state), next model input (bf16 NHWC, duplicated for CFG)
+__global__ void cfg_ddim_kernel(const float* __restrict__ eps, float* __restrict__ lat, bf16_t* __restrict__ model_in,
+                                const float* __restrict__ coef, int* __restrict__ step, float guidance, int cfg, int B, int C,
+                                long long HW)
+{
+    const long long total = (long long)B * C * HW;
+    const int st = *step;
+    const float s1mat = coef[st * 4 + 0], sat = coef[st * 4 + 1], sap = coef[st * 4 + 2], s1map = coef[st * 4 + 3];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long long b = i / (HW * C);
+        float e;
+        if (cfg) {
+            const float eu = eps[(b * HW + p) * C + c];
+            const float et = eps[((b + B) * HW + p) * C + c];
+            e = eu + guidance * (et - eu);
+        } else {
+            e = eps[(b * HW + p) * C + c];
+        }
+        const float x = lat[i];
+        const float x0 = (x - s1mat * e) / sat;
+        const float xn = sap * x0 + s1map * e;
+        lat[i] = xn;
+        const bf16_t xb = (bf16_t)xn;
+        model_in[(b * HW + p) * C + c] = xb;
+        if (cfg) model_in[((b + B) * HW + p) * C + c] = xb;
+    }
+}
+__global__ void bump_step_kernel(int* step) { *step += 1; }
+__global__ void latents_to_model_input_kernel(const float* __restrict__ lat, bf16_t* __restrict__ model_in, float mul, int rep,
+                                              int B, int C, long long HW)
+{
+    const long long total = (long long)B * C * HW;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long long b = i / (HW * C);
+        const bf16_t v = (bf16_t)(lat[i] * mul);
+        for (int r = 0; r < rep; ++r) model_in[((b + (long long)r * B) * HW + p) * C + c] = v;
+    }
+}
+__global__ void postprocess_kernel(const float* __restrict__ x, float* __restrict__ o32, uint8_t* __restrict__ o8, int C,
+                                   long long HW, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long long p = (i / C) % HW, n = i / (C * HW);
+        float v = x[i] / 2.0f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        if (o32) o32[(n * C + c) * HW + p] = v;
+        if (o8) o8[i] = (uint8_t)rintf(v * 255.0f);
+    }
+}
+
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ d, int R, int C)
+{
+    __shared__ bf16_t tile[32][33];
+    const long long base = (long long)blockIdx.z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[j][threadIdx.x] = s[base + (long long)r * C + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < C) d[base + (long long)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+__global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ lat, float scale,
+                                  int C, long long HW, long long total)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long long n = i / (HW * C);
+        const float mean = mom[(n * HW + p) * 2 * C + c];
+        float lv = mom[(n * HW + p) * 2 * C + C + c];
+        lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+        lat[i] = (mean + expf(0.5f * lv) * noise[i]) * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" int dc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream)
+{
+    if (!src || !dst) return DC_ERR_INVALID;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, C, (long long)H * W, total);
+    return dc_launch_status();
+}
+extern "C" int dc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, void* stream)
+{
+    if (!src || !dst) return DC_ERR_INVALID;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, C, (long long)H * W, total);
+    return dc_launch_status();
+}
+extern "C" int dc_nhwc_f32_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, void* stream)
+{
+    if (!src || !dst) return DC_ERR_INVALID;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dst, C, (long long)H * W, total);
+    return dc_launch_status();
+}
+extern "C" int dc_f32_to_bf16(const float* src, void* dst, long long n, void* stream)
+{
+    if (!src || !dst || n <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    return dc_launch_status();
+}
+extern "C" int dc_silu_f32(const float* x, float* y, long long n, void* stream)
+{
+    if (!x || !y || n <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return dc_launch_status();
+}
+extern "C" int dc_add_bf16(const void* a, const void* b, void* y, long long n, void* stream)
+{
+    if (!a || !b || !y || n <= 0 || (n & 7)) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n / 8);
+    return dc_launch_status();
+}
+extern "C" int dc_timestep_embedding_f32(const float* t_dev, const int* step_dev, float* out, int n, int dim, void* stream)
+{
+    if (!t_dev || !out || n <= 0 || dim <= 0 || (dim & 1)) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(dc_cdiv((long long)n * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t_dev, step_dev, out, n, dim);
+    return dc_launch_status();
+}
+extern "C" int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream)
+{
+    if (!src || !dst || batch <= 0 || R <= 0 || C <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(dc_cdiv(C, 32), dc_cdiv(R, 32), batch), dim3(32, 8), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, R, C);
+    return dc_launch_status();
+}
+extern "C" int dc_vae_sample_latents(const float* moments, const float* noise, float* latents, float scale, int N, int C, int H, int W, void* stream)
+{
+    if (!moments || !noise || !latents) return DC_ERR_INVALID;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, moments, noise, latents, scale, C, (long long)H * W, total);
+    return dc_launch_status();
+}
+extern "C" int dc_cfg_ddim_step(const float* eps, float* latents, void* model_in, const float* coef_dev, int* step_dev,
+                                float guidance, int cfg, int B, int C, int H, int W, void* stream)
+{
+    if (!eps || !latents || !model_in || !coef_dev || !step_dev || B <= 0) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, st, eps, latents, (bf16_t*)model_in,
+                       coef_dev, step_dev, guidance, cfg, B, C, (long long)H * W);
+    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return dc_launch_status();
+}
+extern "C" int dc_latents_to_model_input(const float* latents, void* model_in, float mul, int rep, int B, int C, int H, int W, void* stream)
+{
+    if (!latents || !model_in || rep <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(latents_to_model_input_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       latents, (bf16_t*)model_in, mul, rep, B, C, (long long)H * W);
+    return dc_launch_status();
+}
+extern "C" int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W, void* stream)
+{
+    if (!x || (!out_nchw_f32 && !out_nhwc_u8)) return DC_ERR_INVALID;
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out_nchw_f32, out_nhwc_u8, C, (long long)H * W, total);
+    return dc_launch_status();
+}

@@ -1,0 +1,250 @@
+// HBM-bound normalisation kernels for gfx950 (NHWC bf16 activations, fp32 statistics).
+// GroupNorm is split into per-(sample,channel) sums -> per-(sample,channel) scale/shift, so that the affine
+// (+SiLU) can be applied inside the consuming conv's load stage (igemm.hip) and so that the channel concat of
+// UNet skip connections never has to be materialised.  Replaces nn.GroupNorm / nn.LayerNorm inside the
+// diffusers blocks called from flownet.py:87-118, pipeline.py:358-367,391 and FDN (control_utils.py:24-34).
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+// Per-(n,c) sum and sum of squares.  grid = (pixel chunks, N); each thread owns one 8-channel vector column and
+// strides over pixels; partials meet in LDS, then one global atomic pair per channel per workgroup.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums,
+                                                       long long HW, int C, int pix_per_block)
+{
+    extern __shared__ float red[];                 // [C][2]
+    const int nv = C >> 3;
+    const int n = blockIdx.y;
+    const long long p_begin = (long long)blockIdx.x * pix_per_block;
+    const long long p_end = min(HW, p_begin + pix_per_block);
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int tpp = min(nv, 256);                  // threads per pixel
+    const int ppb = 256 / tpp;                     // pixels in flight
+    const int vl = threadIdx.x % tpp, pl = threadIdx.x / tpp;
+    if (pl < ppb) {
+        for (int v = vl; v < nv; v += tpp) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+            for (long long p = p_begin + pl; p < p_end; p += ppb) {
+                const u32x4 raw = *(const u32x4*)(x + ((long long)n * HW + p) * C + v * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = __uint_as_float(raw[j] << 16);
+                    const float hi = __uint_as_float(raw[j] & 0xffff0000u);
+                    s[2 * j] += lo;
+                    ss[2 * j] += lo * lo;
+                    s[2 * j + 1] += hi;
+                    ss[2 * j + 1] += hi * hi;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&red[(v * 8 + j) * 2], s[j]);
+                atomicAdd(&red[(v * 8 + j) * 2 + 1], ss[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[(long long)n * C * 2 + i], red[i]);
+}
+
+// One thread per (n, c): sum the group's channel sums (<= a few dozen), emit scale/shift.
+__global__ void gn_finalize_kernel(const float* __restrict__ s1, int C1, const float* __restrict__ s2, int C2,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ ab, int N, int groups, float inv_count, float eps)
+{
+    const int C = C1 + C2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const int cpg = C / groups;
+    const int g0 = (c / cpg) * cpg;
+    float s = 0.f, ss = 0.f;
+    for (int k = g0; k < g0 + cpg; ++k) {
+        const float* p = k < C1 ? s1 + ((long long)n * C1 + k) * 2 : s2 + ((long long)n * C2 + (k - C1)) * 2;
+        s += p[0];
+        ss += p[1];
+    }
+    const float mean = s * inv_count;
+    const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float ga = gamma ? gamma[c] : 1.f;
+    const float be = beta ? beta[c] : 0.f;
+    ab[(long long)i * 2] = rstd * ga;
+    ab[(long long)i * 2 + 1] = be - mean * rstd * ga;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, int C1,
+                                                       const bf16_t* __restrict__ x2, int C2,
+                                                       const float* __restrict__ ab, bf16_t* __restrict__ y,
+                                                       long long HW, long long total_vec, int silu)
+{
+    const int C = C1 + C2;
+    const int nv = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
+        const long long pix = i / nv;
+        const int c = (int)(i - pix * nv) * 8;
+        const int n = (int)(pix / HW);
+        const bf16_t* src = c < C1 ? x1 + pix * C1 + c : x2 + pix * C2 + (c - C1);
+        const u32x4 raw = *(const u32x4*)src;
+        const float* abp = ab + ((long long)n * C + c) * 2;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 g = *(const f32x4*)(abp + 4 * j);
+            float lo = __uint_as_float(raw[j] << 16) * g[0] + g[1];
+            float hi = __uint_as_float(raw[j] & 0xffff0000u) * g[2] + g[3];
+            if (silu) {
+                lo = dc_silu(lo);
+                hi = dc_silu(hi);
+            }
+            bf16x2 p = {(bf16_t)lo, (bf16_t)hi};
+            o[j] = *(uint32_t*)&p;
+        }
+        *(u32x4*)(y + pix * C + c) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+__global__ __launch_bounds__(256) void fdn_modulate_kernel(const bf16_t* __restrict__ x, const float* __restrict__ ab,
+                                                           const bf16_t* __restrict__ gamma,
+                                                           const bf16_t* __restrict__ beta, bf16_t* __restrict__ y,
+                                                           int Bp, long long HW, int C, long long total_vec)
+{
+    const int nv = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
+        const long long pix = i / nv;
+        const int c = (int)(i - pix * nv) * 8;
+        const int n = (int)(pix / HW);
+        const long long ppix = (long long)(n % Bp) * HW + (pix - (long long)n * HW);
+        const bf16x8 xv = *(const bf16x8*)(x + pix * C + c);
+        const bf16x8 gv = *(const bf16x8*)(gamma + ppix * C + c);
+        const bf16x8 bv = *(const bf16x8*)(beta + ppix * C + c);
+        const float* abp = ab + ((long long)n * C + c) * 2;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float nrm = (float)xv[j] * abp[2 * j] + abp[2 * j + 1];
+            o[j] = (bf16_t)(nrm * (1.0f + (float)gv[j]) + (float)bv[j]);
+        }
+        *(bf16x8*)(y + pix * C + c) = o;
+    }
+}
+
+// LayerNorm: one wave per row, values kept in registers (C <= 64*8*MAXV).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        long long M, int C, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 3;
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nv) {
+            const bf16x8 r = *(const bf16x8*)(x + row * C + vi * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[k][j] = (float)r[j];
+                s += v[k][j];
+            }
+        }
+    }
+    const float mean = dc_wave_sum(s) / C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[k][j] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(dc_wave_sum(ss) / C + eps);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nv) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = vi * 8 + j;
+                o[j] = (bf16_t)((v[k][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *(bf16x8*)(y + row * C + vi * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dc_gn_stats_nhwc_bf16(const void* x, float* sums, int N, long long HW, int C, void* stream)
+{
+    if (!x || !sums || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 8192) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st) != hipSuccess) return DC_ERR_LAUNCH;
+    // up to 512 pixel chunks per sample: enough workgroups to stream at HBM rate, few enough final atomics
+    long long chunks = HW / 128;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 512) chunks = 512;
+    const int ppb = (int)((HW + chunks - 1) / chunks);
+    const dim3 grid(dc_cdiv(HW, ppb), N);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)C * 2 * sizeof(float), st, (const bf16_t*)x, sums, HW, C, ppb);
+    return dc_launch_status();
+}
+
+extern "C" int dc_gn_finalize(const float* sums1, int C1, const float* sums2, int C2, const float* gamma,
+                              const float* beta, float* ab, int N, int groups, long long HW, float eps, void* stream)
+{
+    const int C = C1 + C2;
+    if (!sums1 || !ab || N <= 0 || groups <= 0 || C <= 0 || C % groups || (C2 && !sums2)) return DC_ERR_INVALID;
+    const float inv_count = 1.0f / ((float)HW * (float)(C / groups));
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(dc_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums1, C1, sums2, C2, gamma, beta, ab, N, groups, inv_count, eps);
+    return dc_launch_status();
+}
+
+extern "C" int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* ab, void* y, int N,
+                                     long long HW, int silu, void* stream)
+{
+    const int C = C1 + C2;
+    if (!x1 || !ab || !y || N <= 0 || HW <= 0 || (C1 & 7) || (C2 & 7) || (C2 && !x2)) return DC_ERR_INVALID;
+    const long long total_vec = (long long)N * HW * (C >> 3);
+    const int grid = (int)min((long long)4096, (total_vec + 255) / 256);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x1, C1,
+                       (const bf16_t*)x2, C2, ab, (bf16_t*)y, HW, total_vec, silu);
+    return dc_launch_status();
+}
+
+extern "C" int dc_fdn_modulate_nhwc_bf16(const void* x, const float* ab, const void* gamma, const void* beta, void* y,
+                                         int N, int Bp, long long HW, int C, void* stream)
+{
+    if (!x || !ab || !gamma || !beta || !y || N <= 0 || Bp <= 0 || HW <= 0 || (C & 7)) return DC_ERR_INVALID;
+    const long long total_vec = (long long)N * HW * (C >> 3);
+    const int grid = (int)min((long long)4096, (total_vec + 255) / 256);
+    hipLaunchKernelGGL(fdn_modulate_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ab,
+                       (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, Bp, HW, C, total_vec);
+    return dc_launch_status();
+}
+
+extern "C" int dc_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, long long M, int C,
+                                 float eps, void* stream)
+{
+    if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || (C & 7) || C > 64 * 8 * 4) return DC_ERR_INVALID;
+    const dim3 grid(dc_cdiv(M, 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    return dc_launch_status();
+}

@@ -1,0 +1,194 @@
+// Forward (summation) splatting for gfx950, fp32 NCHW — the one native kernel the reference owns
+// (`softsplat_out`, controlnet/softsplat.py:285-335) plus the wrapper math around it:
+//   'soft' mode (softsplat.py:246-247,253-270), compute_mask (control_utils.py:11-17),
+//   FeatureWarperSoftsplat's mask multiply (control_utils.py:69-70), flow resize+normalise
+//   (control_utils.py:74-97) and the confidence fusion / hole fill of extractors.py:297-310.
+// HBM-bound scatter: one thread per source element, float atomics (agent scope by default), consecutive lanes =
+// consecutive x so that a wave's four corner adds form (mostly) contiguous segments for smooth flow.
+// exp(metric) and the extra normaliser channel are produced on the fly: the reference's cat[in*exp(m), exp(m)]
+// tensor is never materialised, and the normalise + mask pass is fused into one kernel.
+// Summation order of colliding sources is atomic-arrival order, exactly as in the reference's CUDA kernel.
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+// acc [N][Cacc][H][W]; channel c < C takes in*e, channel C (if SOFT) takes e.  e = exp(metric) or 1.
+template <bool SOFT, bool CONST_METRIC>
+__global__ __launch_bounds__(256) void splat_scatter_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                            const float* __restrict__ metric, float* __restrict__ acc,
+                                                            int N, int C, int H, int W, float const_e)
+{
+    const int Cacc = SOFT ? C + 1 : C;
+    const long long total = (long long)N * Cacc * H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((long long)W * H)) % Cacc);
+        const int n = (int)(i / ((long long)W * H * Cacc));
+        const long long hw = (long long)H * W;
+        const long long p = (long long)y * W + x;
+        const float fx = (float)x + flow[((long long)n * 2 + 0) * hw + p];      // softsplat.py:298-299
+        const float fy = (float)y + flow[((long long)n * 2 + 1) * hw + p];
+        if (!isfinite(fx) || !isfinite(fy)) continue;                            // :301-302
+        float v;
+        if (SOFT) {
+            const float e = CONST_METRIC ? const_e : expf(metric[(long long)n * hw + p]);
+            v = c < C ? in[((long long)n * C + c) * hw + p] * e : e;            // :246-247
+        } else {
+            v = in[((long long)n * C + c) * hw + p];
+        }
+        const int nwx = (int)floorf(fx), nwy = (int)floorf(fy);                  // :306-313
+        const int sex = nwx + 1, sey = nwy + 1;
+        const float wnw = ((float)sex - fx) * ((float)sey - fy);                 // :315-318
+        const float wne = (fx - (float)nwx) * ((float)sey - fy);
+        const float wsw = ((float)sex - fx) * (fy - (float)nwy);
+        const float wse = (fx - (float)nwx) * (fy - (float)nwy);
+        float* o = acc + ((long long)n * Cacc + c) * hw;
+        const bool x0 = nwx >= 0 && nwx < W, x1 = sex >= 0 && sex < W;
+        const bool y0 = nwy >= 0 && nwy < H, y1 = sey >= 0 && sey < H;
+        if (x0 && y0) atomicAdd(o + (long long)nwy * W + nwx, v * wnw);          // :320-334
+        if (x1 && y0) atomicAdd(o + (long long)nwy * W + sex, v * wne);
+        if (x0 && y1) atomicAdd(o + (long long)sey * W + nwx, v * wsw);
+        if (x1 && y1) atomicAdd(o + (long long)sey * W + sex, v * wse);
+    }
+}
+
+// out[n][c] = acc[n][c] / (acc[n][C] + 1e-7) [* (1 - mask)]
+__global__ __launch_bounds__(256) void splat_normalize_kernel(const float* __restrict__ acc, const float* __restrict__ mask,
+                                                              float* __restrict__ out, int N, int C, int H, int W)
+{
+    const long long hw = (long long)H * W;
+    const long long total = (long long)N * C * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % hw;
+        const int c = (int)((i / hw) % C);
+        const int n = (int)(i / (hw * C));
+        const float den = acc[((long long)n * (C + 1) + C) * hw + p] + 0.0000001f;   // softsplat.py:256-257
+        float v = acc[((long long)n * (C + 1) + c) * hw + p] / den;                  // :270
+        if (mask) v = v * (1.0f - mask[(long long)n * hw + p]);                      // control_utils.py:69-70
+        out[i] = v;
+    }
+}
+
+// occ = (|| b + warped(a by b) ||_2 > 0.3)   control_utils.py:15-16 ; acc [N][3][H][W]
+__global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict__ acc, const float* __restrict__ fb,
+                                                        float* __restrict__ mask, int N, int H, int W)
+{
+    const long long hw = (long long)H * W;
+    const long long total = (long long)N * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % hw;
+        const long long n = i / hw;
+        const float den = acc[(n * 3 + 2) * hw + p] + 0.0000001f;
+        const float dx = fb[(n * 2 + 0) * hw + p] + acc[(n * 3 + 0) * hw + p] / den;
+        const float dy = fb[(n * 2 + 1) * hw + p] + acc[(n * 3 + 1) * hw + p] / den;
+        mask[i] = sqrtf(dx * dx + dy * dy) > 0.3f ? 1.0f : 0.0f;
+    }
+}
+
+// F.interpolate(bilinear, align_corners=False) + per-component division  (control_utils.py:87-96)
+__global__ __launch_bounds__(256) void flow_resize_kernel(const float* __restrict__ src, long long sbs, float* __restrict__ dst,
+                                                          int N, int H, int W, int h, int w)
+{
+    const long long total = (long long)N * 2 * h * w;
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    const float norm_w = (float)(w - 1) / 2.0f, norm_h = (float)(h - 1) / 2.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % w), oy = (int)((i / w) % h);
+        const int c = (int)((i / ((long long)w * h)) % 2);
+        const long long n = i / ((long long)w * h * 2);
+        float fy = sy * ((float)oy + 0.5f) - 0.5f;
+        float fx = sx * ((float)ox + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* s = src + n * sbs + (long long)c * H * W;
+        const float v = hy * (hx * s[(long long)y0 * W + x0] + lx * s[(long long)y0 * W + x1]) +
+                        ly * (hx * s[(long long)y1 * W + x0] + lx * s[(long long)y1 * W + x1]);
+        dst[i] = v / (c == 0 ? norm_w : norm_h);
+    }
+}
+
+// extractors.py:297-310
+__global__ __launch_bounds__(256) void fuse_kernel(const float* __restrict__ wf, const float* __restrict__ wl,
+                                                   const float* __restrict__ cf, const float* __restrict__ cb,
+                                                   const float* __restrict__ of, const float* __restrict__ ob,
+                                                   float* __restrict__ fused, int N, int C, long long hw)
+{
+    const long long total = (long long)N * C * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % hw;
+        const long long n = i / (hw * C);
+        const float a = fmaxf(cf[n * hw + p], 0.f), b = fmaxf(cb[n * hw + p], 0.f);
+        const float wsum = (a + b) + 1e-6f;
+        float v = (a / wsum) * wf[i] + (b / wsum) * wl[i];
+        if (of[n * hw + p] + ob[n * hw + p] > 1.5f) v = 0.5f * (wf[i] + wl[i]);
+        fused[i] = v;
+    }
+}
+
+inline int grid_for(long long total) { return (int)min((long long)8192, (total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int dc_splat_sum_f32(const float* in, const float* flow, float* out, int N, int C, int H, int W, void* stream)
+{
+    if (!in || !flow || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * C * H * W;
+    if (hipMemsetAsync(out, 0, (size_t)total * 4, st) != hipSuccess) return DC_ERR_LAUNCH;
+    hipLaunchKernelGGL((splat_scatter_kernel<false, false>), dim3(grid_for(total)), dim3(256), 0, st, in, flow,
+                       (const float*)nullptr, out, N, C, H, W, 1.0f);
+    return dc_launch_status();
+}
+
+extern "C" int dc_splat_soft_f32(const float* in, const float* flow, const float* metric, const float* mask, float* out,
+                                 float* acc_ws, int N, int C, int H, int W, void* stream)
+{
+    if (!in || !flow || !metric || !out || !acc_ws || N <= 0 || C <= 0 || H <= 0 || W <= 0) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * (C + 1) * H * W;
+    if (hipMemsetAsync(acc_ws, 0, (size_t)total * 4, st) != hipSuccess) return DC_ERR_LAUNCH;
+    hipLaunchKernelGGL((splat_scatter_kernel<true, false>), dim3(grid_for(total)), dim3(256), 0, st, in, flow, metric,
+                       acc_ws, N, C, H, W, 1.0f);
+    hipLaunchKernelGGL(splat_normalize_kernel, dim3(grid_for((long long)N * C * H * W)), dim3(256), 0, st, acc_ws, mask,
+                       out, N, C, H, W);
+    return dc_launch_status();
+}
+
+extern "C" int dc_occlusion_mask_f32(const float* flow_a, const float* flow_b, float* mask_out, float* acc_ws, int N,
+                                     int H, int W, void* stream)
+{
+    if (!flow_a || !flow_b || !mask_out || !acc_ws || N <= 0 || H <= 0 || W <= 0) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)N * 3 * H * W;
+    if (hipMemsetAsync(acc_ws, 0, (size_t)total * 4, st) != hipSuccess) return DC_ERR_LAUNCH;
+    // metric = ones -> exp(1) (control_utils.py:12)
+    hipLaunchKernelGGL((splat_scatter_kernel<true, true>), dim3(grid_for(total)), dim3(256), 0, st, flow_a, flow_b,
+                       (const float*)nullptr, acc_ws, N, 2, H, W, expf(1.0f));
+    hipLaunchKernelGGL(occlusion_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, st, acc_ws, flow_b, mask_out, N, H, W);
+    return dc_launch_status();
+}
+
+extern "C" int dc_flow_resize_normalize_f32(const float* src, long long src_batch_stride, float* dst, int N, int H,
+                                            int W, int h, int w, void* stream)
+{
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || h <= 1 || w <= 1) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(flow_resize_kernel, dim3(grid_for((long long)N * 2 * h * w)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_batch_stride, dst, N, H, W, h, w);
+    return dc_launch_status();
+}
+
+extern "C" int dc_fuse_warped_f32(const float* warped_first, const float* warped_last, const float* conf_f,
+                                  const float* conf_b, const float* occ_f, const float* occ_b, float* fused, int N,
+                                  int C, int H, int W, void* stream)
+{
+    if (!warped_first || !warped_last || !conf_f || !conf_b || !occ_f || !occ_b || !fused) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(fuse_kernel, dim3(grid_for((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                       warped_first, warped_last, conf_f, conf_b, occ_f, occ_b, fused, N, C, (long long)H * W);
+    return dc_launch_status();
+}

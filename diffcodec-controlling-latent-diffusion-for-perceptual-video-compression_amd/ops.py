@@ -1,0 +1,391 @@
+"""Thin host wrappers: torch tensors (device memory + stream plumbing) -> C-ABI launchers of libdiffcodec_hip.so.
+
+Activations are NHWC bf16 tensors of shape [N,H,W,C] (a [B,L,C] token sequence is the same memory with H=1, W=L).
+No arithmetic happens in torch on this path; every function below ends in exactly one or more `lib.call`s."""
+import math
+
+import torch
+
+from . import lib
+from .lib import ConvDesc
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous memory")
+    return t
+
+
+# ------------------------------------------------------------------------------------------ weights
+class PackedConv:
+    """Conv / linear weight repacked for the device kernels.
+    kind 'igemm':      w bf16 [Cout][k*k][Cin]
+    kind 'small_cin':  w bf16 [k*k][Cin][Cout]
+    kind 'small_cout': w bf16 [Cout][k*k][Cin]"""
+
+    def __init__(self, weight, bias, device, geglu=False):
+        w = weight.detach().float()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        cout, cin, kh, kw = w.shape
+        assert kh == kw and kh in (1, 3)
+        self.cout, self.cin, self.ksize, self.geglu = cout, cin, kh, geglu
+        b = None if bias is None else bias.detach().float()
+        if cin <= 16:
+            self.kind = "small_cin"
+            wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+        elif cout <= 8:
+            self.kind = "small_cout"
+            wp = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        else:
+            self.kind = "igemm"
+            if cin % 64 or cout % 16:
+                raise ValueError(f"igemm needs Cin%64==0 and Cout%16==0, got {cin}->{cout}")
+            wp = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+            if geglu:
+                # rows interleaved in blocks of 16 hidden | 16 gate so both halves of a GEGLU pair share a wave
+                f = cout // 2
+                assert f % 16 == 0
+                idx = torch.arange(cout).reshape(2, f // 16, 16).permute(1, 0, 2).reshape(-1)
+                wp = wp[idx]
+                if b is not None:
+                    b = b[idx]
+        self.w = wp.contiguous().to(device=device, dtype=BF16)
+        self.bias = None if b is None else b.contiguous().to(device=device, dtype=F32)
+
+
+class PackedConvF32:
+    """fp32 OIHW weights of the control extractors (kept in checkpoint layout)."""
+
+    def __init__(self, weight, bias, device):
+        self.w = weight.detach().float().contiguous().to(device)
+        self.bias = None if bias is None else bias.detach().float().contiguous().to(device)
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+
+
+# ------------------------------------------------------------------------------------------ conv / linear
+def _pick_splitk(m, cout, kt):
+    bn = 160 if cout % 160 == 0 else 128
+    tiles = math.ceil(m / 64) * math.ceil(cout / bn)
+    if tiles >= 128 or kt < 16:
+        return 1
+    return int(max(1, min(16, kt // 8, math.ceil(256 / tiles))))
+
+
+def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
+         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0):
+    """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`."""
+    _chk(x1, BF16, "x1")
+    n, h, w, c1 = x1.shape
+    c2 = 0
+    if x2 is not None:
+        _chk(x2, BF16, "x2")
+        assert x2.shape[:3] == x1.shape[:3]
+        c2 = x2.shape[3]
+    assert c1 + c2 == pc.cin, f"channel mismatch {c1}+{c2} vs {pc.cin}"
+    k = pc.ksize
+    if k == 1:
+        ho, wo = h, w
+    else:
+        hin, win = (2 * h, 2 * w) if upsample else (h, w)
+        ho = (hin + (2 if pad else 1) - 3) // stride + 1
+        wo = (win + (2 if pad else 1) - 3) // stride + 1
+    if pc.kind == "small_cin":
+        assert x2 is None and gn_ab is None and residual is None and row_add is None and not upsample and not out_f32
+        out = torch.empty((n, ho, wo, pc.cout), device=x1.device, dtype=BF16)
+        lib.call("dc_conv_small_cin_bf16", x1.data_ptr(), pc.w.data_ptr(), _ptr(pc.bias), out.data_ptr(), n, h, w, c1,
+                 pc.cout, k, stride, pad if k == 3 else 0, ho, wo, _stream())
+        if out_scale != 1.0:
+            raise ValueError("out_scale unsupported on the small-cin path")
+        return out
+    if pc.kind == "small_cout":
+        assert x2 is None and residual is None and row_add is None and not upsample and stride == 1 and (k == 1 or pad == 1)
+        out = torch.empty((n, h, w, pc.cout), device=x1.device, dtype=F32 if out_f32 else BF16)
+        gb = 0 if gn_ab is None else gn_ab.shape[0]
+        lib.call("dc_conv_small_cout_bf16", x1.data_ptr(), pc.w.data_ptr(), _ptr(pc.bias), _ptr(gn_ab), int(gn_silu), gb,
+                 out.data_ptr(), int(out_f32), n, h, w, c1, pc.cout, k, _stream())
+        return out
+    cout_eff = pc.cout // 2 if pc.geglu else pc.cout
+    out = torch.empty((n, ho, wo, cout_eff), device=x1.device, dtype=F32 if out_f32 else BF16)
+    m = n * ho * wo
+    kt = (9 if k == 3 else 1) * (pc.cin // 64)
+    if splitk is None:
+        splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt)
+    ws = torch.empty((m, pc.cout), device=x1.device, dtype=F32) if splitk > 1 else None
+    if gn_ab is not None:
+        _chk(gn_ab, F32, "gn_ab")
+        assert gn_ab.shape[1] == pc.cin
+    if residual is not None:
+        _chk(residual, BF16, "residual")
+        assert residual.numel() == m * pc.cout
+    ras = 0
+    if row_add is not None:
+        assert row_add.dtype == F32 and row_add.is_cuda and row_add.shape == (n, pc.cout) and row_add.stride(1) == 1
+        ras = row_add.stride(0)
+    d = ConvDesc(x1=x1.data_ptr(), x2=_ptr(x2), w=pc.w.data_ptr(), bias=_ptr(pc.bias), gn_ab=_ptr(gn_ab),
+                 row_add=_ptr(row_add), residual=_ptr(residual), out=out.data_ptr(), splitk_ws=_ptr(ws),
+                 N=n, H=h, W=w, C1=c1, C2=c2, Cout=pc.cout, ksize=k, stride=stride, pad=int(pad), upsample=int(upsample),
+                 Ho=ho, Wo=wo, gn_silu=int(gn_silu), epilogue=1 if pc.geglu else 0, out_f32=int(out_f32),
+                 out_scale=float(out_scale), splitk=int(splitk), gn_batch=0 if gn_ab is None else gn_ab.shape[0],
+                 act=int(act), row_add_stride=int(ras))
+    lib.call("dc_conv_igemm_bf16", d, _stream())
+    return out
+
+
+def linear(x, pc, **kw):
+    """nn.Linear on rows: x [..., Cin] bf16 -> [..., Cout]."""
+    shp = x.shape
+    y = conv(x.reshape(1, 1, -1, shp[-1]), pc, **kw)
+    return y.reshape(*shp[:-1], y.shape[-1])
+
+
+def conv3x3_nchw_f32(x, pc, stride=1, silu=False):
+    """fp32 NCHW conv of the control extractors; x may be a channel-slice view of a contiguous NCHW tensor."""
+    assert x.dtype == F32 and x.is_cuda
+    n, c, h, w = x.shape
+    assert x.stride(3) == 1 and x.stride(2) == w and x.stride(1) == h * w, "need dense CHW planes"
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    y = torch.empty((n, pc.cout, ho, wo), device=x.device, dtype=F32)
+    lib.call("dc_conv3x3_nchw_f32", x.data_ptr(), x.stride(0), pc.w.data_ptr(), _ptr(pc.bias), y.data_ptr(), n, c, h, w,
+             pc.cout, stride, int(silu), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------ norms
+def gn_stats(x):
+    _chk(x, BF16, "x")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    sums = torch.empty((n, c, 2), device=x.device, dtype=F32)
+    lib.call("dc_gn_stats_nhwc_bf16", x.data_ptr(), sums.data_ptr(), n, hw, c, _stream())
+    return sums
+
+
+def gn_finalize(sums1, gamma, beta, groups, hw, eps, sums2=None):
+    n, c1 = sums1.shape[0], sums1.shape[1]
+    c2 = 0 if sums2 is None else sums2.shape[1]
+    ab = torch.empty((n, c1 + c2, 2), device=sums1.device, dtype=F32)
+    lib.call("dc_gn_finalize", sums1.data_ptr(), c1, _ptr(sums2), c2, _ptr(gamma), _ptr(beta), ab.data_ptr(), n, groups,
+             hw, float(eps), _stream())
+    return ab
+
+
+def group_norm_ab(x, gamma, beta, groups, eps, x2=None):
+    """GroupNorm statistics of cat[x, x2] folded with the affine into per-(sample,channel) (scale, shift)."""
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    return gn_finalize(gn_stats(x), gamma, beta, groups, hw, eps, None if x2 is None else gn_stats(x2))
+
+
+def gn_apply(x, ab, silu=False, x2=None):
+    _chk(x, BF16, "x")
+    n, c1 = x.shape[0], x.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    hw = x.numel() // (n * c1)
+    y = torch.empty(x.shape[:-1] + (c1 + c2,), device=x.device, dtype=BF16)
+    lib.call("dc_gn_apply_nhwc_bf16", x.data_ptr(), c1, _ptr(x2), c2, ab.data_ptr(), y.data_ptr(), n, hw, int(silu), _stream())
+    return y
+
+
+def fdn_modulate(x, ab, gamma, beta):
+    _chk(x, BF16, "x")
+    _chk(gamma, BF16, "gamma")
+    _chk(beta, BF16, "beta")
+    n, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (n * c)
+    y = torch.empty_like(x)
+    lib.call("dc_fdn_modulate_nhwc_bf16", x.data_ptr(), ab.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), n,
+             gamma.shape[0], hw, c, _stream())
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    _chk(x, BF16, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    lib.call("dc_layernorm_bf16", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.numel() // c, c, float(eps), _stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention(q, k, v, heads, scale=None):
+    """q [B,Nq,*] k,v [B,Nk,*] bf16 row-strided views (last-dim slices of a fused projection are fine)."""
+    b, nq, c = q.shape
+    nk = k.shape[1]
+    d = c // heads
+    for t in (q, k, v):
+        assert t.dtype == BF16 and t.is_cuda and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
+    out = torch.empty((b, nq, c), device=q.device, dtype=BF16)
+    lib.call("dc_attention_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), b, heads, nq, nk, d,
+             q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale if scale is not None else d ** -0.5), _stream())
+    return out
+
+
+def softmax_rows(s, scale):
+    _chk(s, F32, "s")
+    rows, cols = s.shape
+    p = torch.empty((rows, cols), device=s.device, dtype=BF16)
+    lib.call("dc_softmax_rows_f32_to_bf16", s.data_ptr(), p.data_ptr(), rows, cols, float(scale), _stream())
+    return p
+
+
+# ------------------------------------------------------------------------------------------ layout / misc
+def nchw_f32_to_nhwc_bf16(x):
+    _chk(x, F32, "x")
+    n, c, h, w = x.shape
+    y = torch.empty((n, h, w, c), device=x.device, dtype=BF16)
+    lib.call("dc_nchw_f32_to_nhwc_bf16", x.data_ptr(), y.data_ptr(), n, c, h, w, _stream())
+    return y
+
+
+def nhwc_bf16_to_nchw_f32(x):
+    _chk(x, BF16, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=F32)
+    lib.call("dc_nhwc_bf16_to_nchw_f32", x.data_ptr(), y.data_ptr(), n, c, h, w, _stream())
+    return y
+
+
+def nhwc_f32_to_nchw_f32(x):
+    _chk(x, F32, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=F32)
+    lib.call("dc_nhwc_f32_to_nchw_f32", x.data_ptr(), y.data_ptr(), n, c, h, w, _stream())
+    return y
+
+
+def f32_to_bf16(x):
+    _chk(x, F32, "x")
+    y = torch.empty(x.shape, device=x.device, dtype=BF16)
+    lib.call("dc_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
+def silu_f32(x):
+    _chk(x, F32, "x")
+    y = torch.empty_like(x)
+    lib.call("dc_silu_f32", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
+def add_bf16(a, b):
+    _chk(a, BF16, "a")
+    _chk(b, BF16, "b")
+    y = torch.empty_like(a)
+    lib.call("dc_add_bf16", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream())
+    return y
+
+
+def timestep_embedding(t_dev, n, dim, step_dev=None):
+    _chk(t_dev, F32, "t")
+    out = torch.empty((n, dim), device=t_dev.device, dtype=F32)
+    lib.call("dc_timestep_embedding_f32", t_dev.data_ptr(), _ptr(step_dev), out.data_ptr(), n, dim, _stream())
+    return out
+
+
+def transpose_bf16(x):
+    """[B,R,C] -> [B,C,R]"""
+    _chk(x, BF16, "x")
+    b, r, c = x.shape
+    y = torch.empty((b, c, r), device=x.device, dtype=BF16)
+    lib.call("dc_transpose_bf16", x.data_ptr(), y.data_ptr(), b, r, c, _stream())
+    return y
+
+
+def vae_sample_latents(moments_nhwc_f32, noise, scale):
+    _chk(moments_nhwc_f32, F32, "moments")
+    _chk(noise, F32, "noise")
+    n, c, h, w = noise.shape
+    lat = torch.empty_like(noise)
+    lib.call("dc_vae_sample_latents", moments_nhwc_f32.data_ptr(), noise.data_ptr(), lat.data_ptr(), float(scale), n, c, h, w, _stream())
+    return lat
+
+
+# ------------------------------------------------------------------------------------------ splat stage (fp32 NCHW)
+def splat_soft(x, flow, metric, mask=None):
+    for t, nm in ((x, "in"), (flow, "flow"), (metric, "metric")):
+        _chk(t, F32, nm)
+    n, c, h, w = x.shape
+    assert flow.shape == (n, 2, h, w) and metric.shape == (n, 1, h, w)
+    out = torch.empty_like(x)
+    ws = torch.empty((n, c + 1, h, w), device=x.device, dtype=F32)
+    lib.call("dc_splat_soft_f32", x.data_ptr(), flow.data_ptr(), metric.data_ptr(), _ptr(mask), out.data_ptr(), ws.data_ptr(),
+             n, c, h, w, _stream())
+    return out
+
+
+def splat_sum(x, flow):
+    _chk(x, F32, "in")
+    _chk(flow, F32, "flow")
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    lib.call("dc_splat_sum_f32", x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w, _stream())
+    return out
+
+
+def occlusion_mask(flow_a, flow_b):
+    _chk(flow_a, F32, "flow_a")
+    _chk(flow_b, F32, "flow_b")
+    n, _, h, w = flow_a.shape
+    m = torch.empty((n, 1, h, w), device=flow_a.device, dtype=F32)
+    ws = torch.empty((n, 3, h, w), device=flow_a.device, dtype=F32)
+    lib.call("dc_occlusion_mask_f32", flow_a.data_ptr(), flow_b.data_ptr(), m.data_ptr(), ws.data_ptr(), n, h, w, _stream())
+    return m
+
+
+def flow_resize_normalize(flow2, th, tw):
+    """flow2: [N,2,H,W] fp32, possibly a channel-slice view of the [N,4,H,W] control."""
+    assert flow2.dtype == F32 and flow2.is_cuda and flow2.shape[1] == 2
+    n, _, h, w = flow2.shape
+    assert flow2.stride(3) == 1 and flow2.stride(2) == w and flow2.stride(1) == h * w
+    out = torch.empty((n, 2, th, tw), device=flow2.device, dtype=F32)
+    lib.call("dc_flow_resize_normalize_f32", flow2.data_ptr(), flow2.stride(0), out.data_ptr(), n, h, w, th, tw, _stream())
+    return out
+
+
+def fuse_warped(wf, wl, cf, cb, of, ob):
+    n, c, h, w = wf.shape
+    out = torch.empty_like(wf)
+    lib.call("dc_fuse_warped_f32", wf.data_ptr(), wl.data_ptr(), cf.data_ptr(), cb.data_ptr(), of.data_ptr(), ob.data_ptr(),
+             out.data_ptr(), n, c, h, w, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ scheduler step / io
+def cfg_ddim_step(eps, latents, model_in, coef_dev, step_dev, guidance, cfg):
+    b, c, h, w = latents.shape
+    lib.call("dc_cfg_ddim_step", eps.data_ptr(), latents.data_ptr(), model_in.data_ptr(), coef_dev.data_ptr(),
+             step_dev.data_ptr(), float(guidance), int(cfg), b, c, h, w, _stream())
+
+
+def latents_to_model_input(latents, mul=1.0, rep=1, out=None):
+    _chk(latents, F32, "latents")
+    b, c, h, w = latents.shape
+    if out is None:
+        out = torch.empty((rep * b, h, w, c), device=latents.device, dtype=BF16)
+    lib.call("dc_latents_to_model_input", latents.data_ptr(), out.data_ptr(), float(mul), rep, b, c, h, w, _stream())
+    return out
+
+
+def postprocess_image(x_nhwc_f32, want_u8=False):
+    _chk(x_nhwc_f32, F32, "x")
+    n, h, w, c = x_nhwc_f32.shape
+    o32 = torch.empty((n, c, h, w), device=x_nhwc_f32.device, dtype=F32)
+    o8 = torch.empty((n, h, w, c), device=x_nhwc_f32.device, dtype=torch.uint8) if want_u8 else None
+    lib.call("dc_postprocess_image", x_nhwc_f32.data_ptr(), o32.data_ptr(), _ptr(o8), n, c, h, w, _stream())
+    return o32, o8

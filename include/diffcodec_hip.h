@@ -1,0 +1,160 @@
+/*
+ * diffcodec_hip.h — C-ABI of the MI355X (gfx950) decode hot path of DiffCodec.
+ *
+ * One shared object (libdiffcodec_hip.so) of `extern "C"` launchers.  Every entry point:
+ *   - takes plain device pointers + sizes (no torch / C++ types), the HIP stream as `void*`;
+ *   - allocates nothing and keeps no global state (workspaces are passed in);
+ *   - enqueues on the given stream and returns immediately: 0 = ok, -1 = invalid argument,
+ *     -2 = launch failure.  Safe to capture into a hipGraph.
+ *
+ * Tensor conventions: activations of the diffusion models are NHWC bf16 ("pixel rows x channels");
+ * the control-pyramid stage (extractor + splat) is NCHW fp32 like the reference (softsplat.py:279
+ * forces fp32).  Weights: conv [Cout][KH*KW][Cin] bf16 (repacked from the checkpoint's OIHW), linear
+ * [Cout][Cin] bf16 (checkpoint layout).
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference repo).
+ * The reference's only native interface on this path is the CuPy launch of `softsplat_out`
+ * (controlnet/softsplat.py:284-345); everything else is reached through torch / diffusers module
+ * calls, cited by call site.
+ */
+#ifndef DIFFCODEC_HIP_H
+#define DIFFCODEC_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ forward splatting (fp32, NCHW) */
+/* Replaces cuda_launch(cuda_kernel('softsplat_out', ...)) — controlnet/softsplat.py:284-345 — together
+ * with the 'soft' wrapper math of softsplat.py:246-247,253-270 and the optional `warped*(1-mask)` of
+ * control_utils.py:69-70.  acc_ws: fp32 [N,C+1,H,W] scratch.  metric [N,1,H,W]; mask [N,1,H,W] or NULL. */
+int dc_splat_soft_f32(const float* in, const float* flow, const float* metric, const float* mask,
+                      float* out, float* acc_ws, int N, int C, int H, int W, void* stream);
+/* 'sum' mode: out = splat(in, flow) (softsplat.py:235,251).  out is zeroed here. */
+int dc_splat_sum_f32(const float* in, const float* flow, float* out, int N, int C, int H, int W, void* stream);
+/* compute_mask(a, b) — controlnet/control_utils.py:11-17: occ = (|| b + softsplat(a, b, ones, 'soft') ||_2 > 0.3).
+ * acc_ws: fp32 [N,3,H,W]. */
+int dc_occlusion_mask_f32(const float* flow_a, const float* flow_b, float* mask_out, float* acc_ws,
+                          int N, int H, int W, void* stream);
+/* resize_and_normalize_flow_batched — controlnet/control_utils.py:74-97 (bilinear, align_corners=False,
+ * then u/((w-1)/2), v/((h-1)/2)).  src [N,2,H,W] with batch stride `src_batch_stride` floats (lets the
+ * caller pass flow[:, :2] / flow[:, 2:] views of the [N,4,H,W] control, extractors.py:268-269). */
+int dc_flow_resize_normalize_f32(const float* src, long long src_batch_stride, float* dst,
+                                 int N, int H, int W, int h, int w, void* stream);
+/* Confidence fusion + double-hole fill — controlnet/extractors.py:297-310. All [N,*,H,W] fp32. */
+int dc_fuse_warped_f32(const float* warped_first, const float* warped_last, const float* conf_f,
+                       const float* conf_b, const float* occ_f, const float* occ_b, float* fused,
+                       int N, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------ fp32 NCHW direct conv (extractor) */
+/* nn.Conv2d(k=3, padding=1, stride s) [+ SiLU] of the control extractors — controlnet/extractors.py:215-262,
+ * control_utils.py:43-47.  x [N,Cin,H,W] (batch stride given, for channel-sliced views), w OIHW fp32. */
+int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, const float* w, const float* bias, float* y,
+                        int N, int Cin, int H, int W, int Cout, int stride, int silu, void* stream);
+
+/* ------------------------------------------------------------------ layout / dtype */
+int dc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream);
+int dc_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, void* stream);
+int dc_nhwc_f32_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+int dc_f32_to_bf16(const float* src, void* dst, long long n, void* stream);
+
+/* ------------------------------------------------------------------ MFMA implicit GEMM (bf16 in, fp32 acc) */
+/* One kernel family serves: F.conv2d 3x3 / 1x1 inside diffusers ResnetBlock2D / Downsample2D / Upsample2D /
+ * Transformer2DModel.proj_in/out (call sites flownet.py:83-124, pipeline.py:358-367,391), every nn.Linear
+ * (to_q/k/v/out, ff, time_emb_proj), the FDN gamma/beta convs (control_utils.py:31-32) and the ControlNet
+ * zero-convs (flownet.py:120-128).  Fusions: GroupNorm-affine(+SiLU) on load, nearest-2x upsample on load,
+ * channel-concat of two inputs on load (UNet skip connections), bias + per-sample channel add (time
+ * embedding) + out_scale (conditioning_scale) + residual add, or GEGLU, on store. */
+typedef struct dc_conv_desc {
+    const void* x1;         /* NHWC bf16 [N,H,W,C1] */
+    const void* x2;         /* NHWC bf16 [N,H,W,C2] or NULL (channel concat: cat[x1,x2]) */
+    const void* w;          /* bf16 [Cout][ksize*ksize][C1+C2] */
+    const float* bias;      /* [Cout] or NULL */
+    const float* gn_ab;     /* [gn_batch][C1+C2][2] fp32 (scale, shift) applied on load, or NULL */
+    const float* row_add;   /* [N][Cout] fp32 added per sample (time-embedding projection) or NULL */
+    const void* residual;   /* NHWC bf16 [M][Cout] added after scaling, or NULL */
+    void* out;              /* bf16 [M][Cout] (f32 if out_f32; [M][Cout/2] for GEGLU) */
+    float* splitk_ws;       /* fp32 [M][Cout] when splitk > 1 (zeroed by the launcher) */
+    int N, H, W;            /* input dims (before the fused upsample) */
+    int C1, C2, Cout;
+    int ksize;              /* 1 or 3 */
+    int stride;             /* 1 or 2 */
+    int pad;                /* 1: symmetric pad 1; 0: F.pad(x,(0,1,0,1)) + pad 0 (VAE encoder downsample) */
+    int upsample;           /* 1: F.interpolate(scale_factor=2, nearest) fused on load */
+    int Ho, Wo;             /* output dims */
+    int gn_silu;            /* SiLU after the GN affine */
+    int epilogue;           /* 0: linear; 1: GEGLU (weights/bias rows pre-interleaved 16 hid | 16 gate) */
+    int out_f32;
+    float out_scale;
+    int splitk;             /* >= 1 */
+    int gn_batch;           /* rows of gn_ab (sample n uses row n % gn_batch) */
+    int act;                /* 0 none, 1 SiLU — applied after bias/row_add, before out_scale */
+    long long row_add_stride; /* floats between consecutive samples of row_add (0 = Cout) */
+} dc_conv_desc;
+int dc_conv_igemm_bf16(const dc_conv_desc* desc, void* stream);
+/* Workspace bytes needed for splitk>1 (0 otherwise). */
+long long dc_conv_igemm_ws_bytes(const dc_conv_desc* desc);
+
+/* Small-channel direct convs (NHWC bf16): Cin <= 8 (conv_in 4->320, VAE conv_in) and Cout <= 8
+ * (conv_out 320->4, VAE conv_out 128->3 / 512->8, quant convs).  Same fusions on load as the igemm.
+ * w_small_cin: bf16 [k*k][Cin][Cout]; w_small_cout: bf16 [Cout][k*k][Cin]. */
+int dc_conv_small_cin_bf16(const void* x, const void* w, const float* bias, void* out, int N, int H, int W,
+                           int Cin, int Cout, int ksize, int stride, int pad, int Ho, int Wo, void* stream);
+int dc_conv_small_cout_bf16(const void* x, const void* w, const float* bias, const float* gn_ab, int gn_silu,
+                            int gn_batch, void* out, int out_f32, int N, int H, int W, int Cin, int Cout, int ksize,
+                            void* stream);
+
+/* ------------------------------------------------------------------ normalisation */
+/* GroupNorm (diffusers ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out; FDN.param_free_norm,
+ * control_utils.py:24,29): per-(sample,channel) sums -> per-(sample,channel) scale/shift.
+ * sums [N][C][2] fp32 must be zero on entry (dc_gn_stats zeroes it itself). */
+int dc_gn_stats_nhwc_bf16(const void* x, float* sums, int N, long long HW, int C, void* stream);
+/* Combines channel sums of cat[x1,x2] into `groups` groups; writes ab [N][C1+C2][2]. gamma/beta may be NULL
+ * (affine=False, FDN). */
+int dc_gn_finalize(const float* sums1, int C1, const float* sums2, int C2, const float* gamma, const float* beta,
+                   float* ab, int N, int groups, long long HW, float eps, void* stream);
+/* y = (x*a+b) [SiLU]; x = cat[x1,x2] NHWC bf16. */
+int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* ab, void* y,
+                          int N, long long HW, int silu, void* stream);
+/* FDN modulation — control_utils.py:33: y = (x*a+b)*(1+gamma)+beta; gamma/beta NHWC bf16 [Bp,HW,C] (sample n uses n % Bp). */
+int dc_fdn_modulate_nhwc_bf16(const void* x, const float* ab, const void* gamma, const void* beta, void* y,
+                              int N, int Bp, long long HW, int C, void* stream);
+/* nn.LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3). x [M][C] bf16. */
+int dc_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, long long M, int C, float eps,
+                      void* stream);
+
+/* ------------------------------------------------------------------ attention */
+/* softmax(Q K^T * scale) V, flash-style, heads interleaved on the channel dim (diffusers Attention /
+ * F.scaled_dot_product_attention inside BasicTransformerBlock.attn1/attn2).  q [B][Nq][q_stride] etc.;
+ * head h occupies columns [h*D, (h+1)*D).  D in {8,16,32,40,64,80,128,160}. */
+int dc_attention_bf16(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk, int D,
+                      long long q_stride, long long k_stride, long long v_stride, long long o_stride, float scale,
+                      void* stream);
+/* Row softmax fp32 -> bf16 (VAE single-head attention, d=512, done as GEMM/softmax/GEMM). */
+int dc_softmax_rows_f32_to_bf16(const float* s, void* p, long long rows, int cols, float scale, void* stream);
+
+/* ------------------------------------------------------------------ elementwise */
+/* time_proj — flownet.py:74: sinusoidal embedding of the timestep t_dev[step_dev ? *step_dev : 0] (device-resident so
+ * that a captured hipGraph of one denoising step can be replayed for every step). */
+int dc_timestep_embedding_f32(const float* t_dev, const int* step_dev, float* out, int n, int dim, void* stream);
+/* dst[c][r] = src[r][c], bf16, batch of `batch` matrices (VAE attention: V -> V^T). */
+int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream);
+/* DiagonalGaussianDistribution.sample() * scale — train_controlnet.py:1081, pipeline.ipynb cell 7:
+ * moments NHWC fp32 [N,h,w,2*C] (mean | logvar), noise NCHW fp32 -> latents NCHW fp32. */
+int dc_vae_sample_latents(const float* moments, const float* noise, float* latents, float scale, int N, int C, int H, int W, void* stream);
+int dc_silu_f32(const float* x, float* y, long long n, void* stream);
+int dc_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+/* CFG combine + DDIM step — pipeline.py:370-375.  eps fp32 NHWC [cfg?2B:B][h][w][4]; latents fp32 NCHW in/out;
+ * coef_dev [steps][4] = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_dev int32 counter (incremented).
+ * Also writes the next model input NHWC bf16 [cfg?2B:B][h][w][C]. */
+int dc_cfg_ddim_step(const float* eps, float* latents, void* model_in, const float* coef_dev, int* step_dev,
+                     float guidance, int cfg, int B, int C, int H, int W, void* stream);
+/* latents NCHW f32 [B,C,H,W] * mul -> NHWC bf16 [rep*B,H,W,C] (pipeline.py:313-320, :391 scaling) */
+int dc_latents_to_model_input(const float* latents, void* model_in, float mul, int rep, int B, int C, int H, int W, void* stream);
+/* image_processor.postprocess — pipeline.py:397-398: (x/2+0.5).clamp(0,1); x NHWC f32 [N,H,W,3] -> NCHW f32 and/or NHWC u8 */
+int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

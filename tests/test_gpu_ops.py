@@ -1,0 +1,314 @@
+"""GPU parity: every C-ABI launcher against the CPU oracle / a plain torch fp32 reference of the same op, on the
+same seeded inputs.  bf16 kernels: inputs are bf16-rounded first so the fp32 reference sees identical operands;
+tolerance then covers fp32-accumulation order + one bf16 rounding of the output (rel 2^-8)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import ops as o
+    return o
+
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc(x):  # NCHW fp32 cpu -> NHWC bf16 device
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def close(a, b, rtol=2e-2, atol=2e-2):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------- splat stage
+def test_splat_soft_matches_oracle(ops):
+    from oracle import splat as S
+    g = torch.Generator().manual_seed(0)
+    for (n, c, h, w) in [(1, 3, 9, 11), (2, 21, 32, 32), (2, 161, 64, 64)]:
+        x = torch.randn(n, c, h, w, generator=g)
+        flow = torch.randn(n, 2, h, w, generator=g) * 3
+        flow[0, 0, 0, 0] = float("inf")
+        flow[-1, 1, 1, 2] = float("nan")
+        m = torch.randn(n, 1, h, w, generator=g) * 0.5
+        mask = (torch.rand(n, 1, h, w, generator=g) > 0.5).float()
+        ref = S.softsplat(x, flow, m, "soft") * (1 - mask)
+        out = ops.splat_soft(x.to(DEV), flow.to(DEV), m.to(DEV), mask.to(DEV)).cpu()
+        close(out, ref, rtol=1e-4, atol=1e-5)      # fp32; only the atomic summation order differs
+        ref_sum = S.splat_sum(x, flow)
+        close(ops.splat_sum(x.to(DEV), flow.to(DEV)).cpu(), ref_sum, rtol=1e-4, atol=1e-5)
+
+
+def test_occlusion_mask_and_flow_resize(ops):
+    from oracle import control_ref as C
+    g = torch.Generator().manual_seed(1)
+    flow = torch.randn(2, 4, 128, 128, generator=g) * 6
+    for r in (16, 8, 32):
+        ref = C.resize_and_normalize_flow(flow[:, :2], r, r)
+        out = ops.flow_resize_normalize(flow.to(DEV)[:, :2], r, r).cpu()
+        close(out, ref, rtol=1e-5, atol=1e-5)
+        ref2 = C.resize_and_normalize_flow(flow[:, 2:], r, r)
+        close(ops.flow_resize_normalize(flow.to(DEV)[:, 2:], r, r).cpu(), ref2, rtol=1e-5, atol=1e-5)
+    fa = torch.randn(2, 2, 32, 32, generator=g) * 0.6
+    fb = -fa + 0.25 * torch.randn(2, 2, 32, 32, generator=g)
+    ref = C.compute_mask(fa, fb)
+    out = ops.occlusion_mask(fa.to(DEV), fb.to(DEV)).cpu()
+    # threshold compare: allow disagreement only where the norm is within 1e-4 of 0.3
+    assert (out != ref).float().mean().item() < 2e-3
+    assert 0.05 < ref.mean() < 0.95
+
+
+def test_fuse_warped(ops):
+    g = torch.Generator().manual_seed(2)
+    n, c, h, w = 2, 7, 8, 8
+    wf, wl = torch.randn(n, c, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    cf, cb = torch.randn(n, 1, h, w, generator=g), torch.randn(n, 1, h, w, generator=g)
+    of, ob = (torch.rand(n, 1, h, w, generator=g) > 0.5).float(), (torch.rand(n, 1, h, w, generator=g) > 0.5).float()
+    conf = torch.clamp(torch.cat([cf, cb], 1), min=0)
+    wn = conf / (conf.sum(1, keepdim=True) + 1e-6)
+    ref = wn[:, :1] * wf + wn[:, 1:] * wl
+    ref = torch.where(((of + ob) > 1.5).expand_as(ref), 0.5 * (wf + wl), ref)
+    out = ops.fuse_warped(*(t.to(DEV) for t in (wf, wl, cf, cb, of, ob))).cpu()
+    close(out, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,hw,stride,silu", [(3, 16, 40, 1, True), (16, 32, 33, 2, True), (64, 160, 16, 2, True),
+                                                      (160, 64, 8, 1, True), (64, 1, 8, 1, False), (80, 160, 8, 1, False)])
+def test_conv3x3_nchw_f32(ops, cin, cout, hw, stride, silu):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, cin + 2, hw, hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    xs = x[:, 1:1 + cin]                                  # channel-slice view, like cond[:, 3:]
+    ref = F.conv2d(xs, w, b, stride=stride, padding=1)
+    if silu:
+        ref = F.silu(ref)
+    pc = ops.PackedConvF32(w, b, DEV)
+    out = ops.conv3x3_nchw_f32(x.to(DEV)[:, 1:1 + cin], pc, stride=stride, silu=silu).cpu()
+    close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- igemm
+CONV_CASES = [
+    # n, h, w, c1, c2, cout, k, stride, pad, upsample
+    (2, 16, 16, 64, 0, 64, 3, 1, 1, False),
+    (2, 16, 16, 128, 0, 160, 3, 1, 1, False),
+    (1, 13, 9, 64, 0, 48, 3, 1, 1, False),          # ragged M, Cout not a tile multiple
+    (2, 16, 16, 64, 64, 128, 3, 1, 1, False),       # channel concat
+    (2, 16, 16, 128, 0, 128, 3, 2, 1, False),       # stride 2
+    (1, 16, 16, 64, 0, 64, 3, 2, 0, False),         # asymmetric pad (VAE encoder)
+    (1, 8, 8, 64, 0, 128, 3, 1, 1, True),           # fused nearest-2x upsample
+    (2, 8, 8, 320, 0, 320, 1, 1, 1, False),         # 1x1
+    (2, 64, 64, 320, 0, 320, 3, 1, 1, False),       # UNet 64x64 ResBlock conv (large tile path)
+    (2, 8, 8, 1280, 1280, 1280, 3, 1, 1, False),    # UNet 8x8 up-block conv (split-K path)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_plain(ops, case):
+    n, h, w, c1, c2, cout, k, stride, pad, up = case
+    g = torch.Generator().manual_seed(4)
+    x1 = bf(torch.randn(n, c1, h, w, generator=g))
+    x2 = bf(torch.randn(n, c2, h, w, generator=g)) if c2 else None
+    cin = c1 + c2
+    wt = bf(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = torch.cat([x1, x2], 1) if c2 else x1
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if k == 3 and pad == 0:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    ref = F.conv2d(xin, wt, b, stride=stride, padding=(1 if (k == 3 and pad) else 0))
+    pc = ops.PackedConv(wt, b, DEV)
+    out = ops.conv(nhwc(x1), pc, x2=None if x2 is None else nhwc(x2), stride=stride, pad=pad, upsample=up)
+    close(from_nhwc(out), ref)
+
+
+def test_conv_igemm_asymmetric_operands(ops):
+    """A = identity-like weights with asymmetric data: catches a transposed / permuted fragment map."""
+    n, h, w, c = 1, 8, 16, 64
+    x = torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) % 251 - 125
+    wt = torch.zeros(64, c, 1, 1)
+    for o in range(64):
+        wt[o, (o * 7 + 3) % c, 0, 0] = 1.0 + (o % 5)
+    ref = F.conv2d(x, wt)
+    out = ops.conv(nhwc(x), ops.PackedConv(wt, None, DEV))
+    assert torch.equal(from_nhwc(out), bf(ref))     # exact: integers below 2^8 scale
+
+
+def test_conv_igemm_fused_epilogues(ops):
+    g = torch.Generator().manual_seed(5)
+    n, h, w, cin, cout = 2, 16, 16, 128, 160
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.1
+    temb = torch.randn(n, cout, generator=g)
+    res = bf(torch.randn(n, cout, h, w, generator=g))
+    gamma, beta = 1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    # reference: GN -> SiLU -> (bf16 operand) -> conv -> +bias +temb -> *scale -> +res
+    y = F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))
+    ref = (F.conv2d(bf(y), wt, b, padding=1) + temb[:, :, None, None]) * 0.75 + res
+    xd = nhwc(x)
+    ab = ops.group_norm_ab(xd, gamma.to(DEV), beta.to(DEV), 32, 1e-5)
+    out = ops.conv(xd, ops.PackedConv(wt, b, DEV), gn_ab=ab, gn_silu=True, row_add=temb.to(DEV), residual=nhwc(res), out_scale=0.75)
+    close(from_nhwc(out), ref, rtol=3e-2, atol=3e-2)
+    out32 = ops.conv(xd, ops.PackedConv(wt, b, DEV), gn_ab=ab, gn_silu=True, row_add=temb.to(DEV), residual=nhwc(res),
+                     out_scale=0.75, out_f32=True)
+    close(out32.cpu().permute(0, 3, 1, 2), ref, rtol=2e-2, atol=2e-2)
+    # forced split-K gives the same answer
+    outk = ops.conv(xd, ops.PackedConv(wt, b, DEV), gn_ab=ab, gn_silu=True, row_add=temb.to(DEV), residual=nhwc(res),
+                    out_scale=0.75, splitk=3)
+    close(from_nhwc(outk), ref, rtol=3e-2, atol=3e-2)
+
+
+def test_linear_and_geglu(ops):
+    g = torch.Generator().manual_seed(6)
+    m, c = 300, 320
+    x = bf(torch.randn(2, m, c, generator=g))
+    w1 = bf(torch.randn(8 * c, c, generator=g) / math.sqrt(c))
+    b1 = torch.randn(8 * c, generator=g) * 0.1
+    hg = F.linear(x, w1, b1)
+    hid, gate = hg.chunk(2, -1)
+    ref = hid * F.gelu(gate)
+    out = ops.linear(x.to(DEV, torch.bfloat16), ops.PackedConv(w1, b1, DEV, geglu=True))
+    assert out.shape == (2, m, 4 * c)
+    close(out.float().cpu(), ref)
+    w2 = bf(torch.randn(c, 4 * c, generator=g) / math.sqrt(4 * c))
+    res = bf(torch.randn(2, m, c, generator=g))
+    ref2 = F.linear(bf(ref), w2) + res
+    out2 = ops.linear(out, ops.PackedConv(w2, None, DEV), residual=res.to(DEV, torch.bfloat16))
+    close(out2.float().cpu(), ref2, rtol=3e-2, atol=3e-2)
+
+
+def test_small_channel_convs(ops):
+    g = torch.Generator().manual_seed(7)
+    x = bf(torch.randn(2, 4, 16, 16, generator=g))
+    w = bf(torch.randn(64, 4, 3, 3, generator=g) / 6)
+    b = torch.randn(64, generator=g) * 0.1
+    out = ops.conv(nhwc(x), ops.PackedConv(w, b, DEV))
+    close(from_nhwc(out), F.conv2d(x, w, b, padding=1))
+    x3 = bf(torch.randn(1, 3, 20, 12, generator=g))
+    w3 = bf(torch.randn(32, 3, 3, 3, generator=g) / 5)
+    close(from_nhwc(ops.conv(nhwc(x3), ops.PackedConv(w3, None, DEV))), F.conv2d(x3, w3, None, padding=1))
+    w1 = bf(torch.randn(4, 4, 1, 1, generator=g) / 2)
+    close(from_nhwc(ops.conv(nhwc(x), ops.PackedConv(w1, b[:4], DEV))), F.conv2d(x, w1, b[:4]))
+    # small cout with fused GN+SiLU and fp32 output (UNet conv_out)
+    xc = bf(torch.randn(2, 64, 16, 16, generator=g))
+    wc = bf(torch.randn(4, 64, 3, 3, generator=g) / 24)
+    bc = torch.randn(4, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ref = F.conv2d(bf(F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))), wc, bc, padding=1)
+    xd = nhwc(xc)
+    ab = ops.group_norm_ab(xd, gamma.to(DEV), beta.to(DEV), 32, 1e-5)
+    out = ops.conv(xd, ops.PackedConv(wc, bc, DEV), gn_ab=ab, gn_silu=True, out_f32=True)
+    close(out.cpu().permute(0, 3, 1, 2), ref, rtol=2e-2, atol=2e-2)
+    w8 = bf(torch.randn(3, 64, 3, 3, generator=g) / 24)
+    close(from_nhwc(ops.conv(xd, ops.PackedConv(w8, None, DEV))), F.conv2d(xc, w8, None, padding=1))
+
+
+# ------------------------------------------------------------------------------------------- norms
+def test_group_norm_paths(ops):
+    g = torch.Generator().manual_seed(8)
+    for (n, c1, c2, hw, groups) in [(2, 64, 0, 16, 32), (2, 320, 0, 32, 32), (1, 1280, 640, 8, 32), (2, 128, 0, 64, 32)]:
+        x1 = bf(torch.randn(n, c1, hw, hw, generator=g) * 2 + 0.5)
+        x2 = bf(torch.randn(n, c2, hw, hw, generator=g)) if c2 else None
+        c = c1 + c2
+        gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+        xin = torch.cat([x1, x2], 1) if c2 else x1
+        ref = F.silu(F.group_norm(xin, groups, gamma, beta, 1e-5))
+        d1, d2 = nhwc(x1), (nhwc(x2) if c2 else None)
+        ab = ops.group_norm_ab(d1, gamma.to(DEV), beta.to(DEV), groups, 1e-5, x2=d2)
+        out = ops.gn_apply(d1, ab, silu=True, x2=d2)
+        close(from_nhwc(out), ref)
+
+
+def test_fdn_modulate(ops):
+    g = torch.Generator().manual_seed(9)
+    n, c, hw = 4, 64, 16
+    x = bf(torch.randn(n, c, hw, hw, generator=g))
+    gam = bf(torch.randn(2, c, hw, hw, generator=g) * 0.3)
+    bet = bf(torch.randn(2, c, hw, hw, generator=g) * 0.3)
+    ref = F.group_norm(x, 32, None, None, 1e-5) * (1 + gam.repeat(2, 1, 1, 1)) + bet.repeat(2, 1, 1, 1)
+    xd = nhwc(x)
+    ab = ops.group_norm_ab(xd, None, None, 32, 1e-5)
+    out = ops.fdn_modulate(xd, ab, nhwc(gam), nhwc(bet))
+    close(from_nhwc(out), ref)
+
+
+def test_layer_norm(ops):
+    g = torch.Generator().manual_seed(10)
+    for c in (64, 320, 640, 1280):
+        x = bf(torch.randn(3, 50, c, generator=g) * 1.5 + 0.3)
+        gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+        ref = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+        out = ops.layer_norm(x.to(DEV, torch.bfloat16), gamma.to(DEV), beta.to(DEV))
+        close(out.float().cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("b,heads,nq,nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
+                                             (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),
+                                             (1, 2, 33, 5, 8), (1, 3, 200, 200, 32), (1, 1, 128, 192, 128)])
+def test_attention(ops, b, heads, nq, nk, d):
+    g = torch.Generator().manual_seed(11)
+    c = heads * d
+    q = bf(torch.randn(b, nq, c, generator=g))
+    k = bf(torch.randn(b, nk, c, generator=g))
+    v = bf(torch.randn(b, nk, c, generator=g))
+    qh, kh, vh = (t.view(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(b, nq, c)
+    out = ops.attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), v.to(DEV, torch.bfloat16), heads)
+    close(out.float().cpu(), ref, rtol=2e-2, atol=1e-2)
+
+
+def test_attention_forced_rescale_and_strided_views(ops):
+    """A key spike late in the sequence forces the online-softmax rescale branch; K/V are slices of one fused tensor."""
+    g = torch.Generator().manual_seed(12)
+    b, heads, n, d = 1, 2, 256, 40
+    c = heads * d
+    q = bf(torch.randn(b, n, c, generator=g))
+    kv = bf(torch.randn(b, n, 2 * c, generator=g))
+    kv[0, 200, :c] = bf(q[0, 17] * 6.0)             # row 17's max jumps at key 200 (4th tile)
+    k, v = kv[..., :c], kv[..., c:]
+    qh, kh, vh = (t.reshape(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(b, n, c)
+    kvd = kv.to(DEV, torch.bfloat16)
+    out = ops.attention(q.to(DEV, torch.bfloat16), kvd[..., :c], kvd[..., c:], heads)
+    close(out.float().cpu(), ref, rtol=2e-2, atol=1e-2)
+
+
+def test_softmax_rows(ops):
+    g = torch.Generator().manual_seed(13)
+    s = torch.randn(37, 4096, generator=g) * 4
+    ref = torch.softmax(s * 0.25, -1)
+    close(ops.softmax_rows(s.to(DEV), 0.25).float().cpu(), ref, rtol=1e-2, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- misc
+def test_layout_and_timestep_embedding(ops):
+    from oracle.sd15_ref import timestep_embedding
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 5, 6, 7, generator=g)
+    y = ops.nchw_f32_to_nhwc_bf16(x.to(DEV))
+    assert torch.equal(from_nhwc(y), bf(x))
+    assert torch.equal(ops.nhwc_bf16_to_nchw_f32(y).cpu(), bf(x))
+    t = torch.tensor([951.0])
+    ref = timestep_embedding(t.expand(3), 320)
+    out = ops.timestep_embedding(t.to(DEV), 3, 320).cpu()
+    close(out, ref, rtol=1e-4, atol=2e-4)
