@@ -1,0 +1,178 @@
+"""Device building blocks shared by the UNet, the ControlNet encoder and the VAE: the diffusers modules the
+reference instantiates (ResnetBlock2D, Transformer2DModel/BasicTransformerBlock, Down/Upsample2D, time embedding),
+re-expressed as sequences of C-ABI launches on NHWC bf16 activations.  Host code only: no arithmetic here.
+
+Weight keys are the diffusers state-dict keys; topology follows the published SD-1.5 modules
+as called from controlnet/flownet.py:74-124 and pipeline.py:358-367."""
+import torch
+
+from . import ops
+from .ops import PackedConv
+
+
+def _f32(sd, key, device):
+    return sd[key].detach().float().contiguous().to(device)
+
+
+class TimeEmbedding:
+    """time_proj + time_embedding MLP (flownet.py:74-75) and ALL ResnetBlock2D.time_emb_proj projections of a model
+    batched into one GEMM: out[n, sum(cout)] fp32, sliced per block (each slice is a `row_add` of that block's conv1).
+    Only SiLU(emb) is ever consumed in SD-1.5, so the SiLU is fused into linear_2's epilogue."""
+
+    def __init__(self, sd, device, ch0, resnet_prefixes):
+        self.ch0 = ch0
+        self.l1 = PackedConv(sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"], device)
+        self.l2 = PackedConv(sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"], device)
+        ws, bs, self.slices, off = [], [], {}, 0
+        for p in resnet_prefixes:
+            w = sd[p + "time_emb_proj.weight"]
+            ws.append(w)
+            bs.append(sd[p + "time_emb_proj.bias"])
+            self.slices[p] = (off, off + w.shape[0])
+            off += w.shape[0]
+        self.proj = PackedConv(torch.cat(ws, 0), torch.cat(bs, 0), device)
+
+    def __call__(self, t_dev, n, step_dev=None):
+        e = ops.timestep_embedding(t_dev, n, self.ch0, step_dev)
+        e = ops.f32_to_bf16(e)
+        e = ops.linear(e, self.l1, act=1)
+        e = ops.linear(e, self.l2, act=1)                       # SiLU(emb)
+        self.all = ops.linear(e, self.proj, out_f32=True)       # [n, total]
+        return self
+
+    def slice(self, prefix):
+        a, b = self.slices[prefix]
+        return self.all[:, a:b]
+
+
+class ResnetBlock:
+    """diffusers ResnetBlock2D: GN -> SiLU -> conv3x3 (+temb) -> GN -> SiLU -> conv3x3, + (1x1 shortcut of) input.
+    Both GroupNorm+SiLU are folded into the following conv's load stage; the channel concat of a UNet skip
+    connection (x2) is read in place by the GN statistics, conv1 and the shortcut."""
+
+    def __init__(self, sd, p, device, groups, eps):
+        self.p, self.groups, self.eps = p, groups, eps
+        self.n1 = (_f32(sd, p + "norm1.weight", device), _f32(sd, p + "norm1.bias", device))
+        self.n2 = (_f32(sd, p + "norm2.weight", device), _f32(sd, p + "norm2.bias", device))
+        self.conv1 = PackedConv(sd[p + "conv1.weight"], sd[p + "conv1.bias"], device)
+        self.conv2 = PackedConv(sd[p + "conv2.weight"], sd[p + "conv2.bias"], device)
+        self.shortcut = None
+        if p + "conv_shortcut.weight" in sd:
+            self.shortcut = PackedConv(sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"], device)
+
+    def __call__(self, x, temb=None, x2=None):
+        ab1 = ops.group_norm_ab(x, self.n1[0], self.n1[1], self.groups, self.eps, x2=x2)
+        h = ops.conv(x, self.conv1, x2=x2, gn_ab=ab1, gn_silu=True, row_add=None if temb is None else temb.slice(self.p))
+        ab2 = ops.group_norm_ab(h, self.n2[0], self.n2[1], self.groups, self.eps)
+        if self.shortcut is not None:
+            sc = ops.conv(x, self.shortcut, x2=x2)
+        else:
+            assert x2 is None
+            sc = x
+        return ops.conv(h, self.conv2, gn_ab=ab2, gn_silu=True, residual=sc)
+
+
+class TransformerBlock:
+    """diffusers Transformer2DModel with one BasicTransformerBlock (SD-1.5: conv proj_in/out, GEGLU feed-forward).
+    to_q/to_k/to_v of the self-attention are one fused GEMM; the cross-attention K/V of the (step-invariant) text
+    embedding are computed once per `set_context` instead of every step."""
+
+    def __init__(self, sd, p, device, heads, groups):
+        self.heads, self.groups = heads, groups
+        self.norm = (_f32(sd, p + "norm.weight", device), _f32(sd, p + "norm.bias", device))
+        self.proj_in = PackedConv(sd[p + "proj_in.weight"], sd[p + "proj_in.bias"], device)
+        self.proj_out = PackedConv(sd[p + "proj_out.weight"], sd[p + "proj_out.bias"], device)
+        q = p + "transformer_blocks.0."
+        self.ln = [(_f32(sd, q + f"norm{i}.weight", device), _f32(sd, q + f"norm{i}.bias", device)) for i in (1, 2, 3)]
+        self.qkv1 = PackedConv(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), None, device)
+        self.out1 = PackedConv(sd[q + "attn1.to_out.0.weight"], sd[q + "attn1.to_out.0.bias"], device)
+        self.q2 = PackedConv(sd[q + "attn2.to_q.weight"], None, device)
+        self.kv2 = PackedConv(torch.cat([sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]], 0), None, device)
+        self.out2 = PackedConv(sd[q + "attn2.to_out.0.weight"], sd[q + "attn2.to_out.0.bias"], device)
+        self.ff1 = PackedConv(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], device, geglu=True)
+        self.ff2 = PackedConv(sd[q + "ff.net.2.weight"], sd[q + "ff.net.2.bias"], device)
+        self.c = self.proj_in.cout
+        self.kv_ctx = None
+
+    def set_context(self, ctx_bf16):
+        """ctx [B,77,768] bf16 -> cached fused K|V [B,77,2C]."""
+        new = ops.linear(ctx_bf16, self.kv2)
+        if self.kv_ctx is not None and self.kv_ctx.shape == new.shape:
+            self.kv_ctx.copy_(new)          # keep the address stable for captured hipGraphs
+        else:
+            self.kv_ctx = new
+
+    def __call__(self, x):
+        n, h, w, c = x.shape
+        ab = ops.group_norm_ab(x, self.norm[0], self.norm[1], self.groups, 1e-6)
+        t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
+        # self-attention
+        y = ops.layer_norm(t, *self.ln[0])
+        qkv = ops.linear(y, self.qkv1)
+        a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads)
+        t = ops.linear(a, self.out1, residual=t)
+        # cross-attention
+        y = ops.layer_norm(t, *self.ln[1])
+        q = ops.linear(y, self.q2)
+        a = ops.attention(q, self.kv_ctx[..., :c], self.kv_ctx[..., c:], self.heads)
+        t = ops.linear(a, self.out2, residual=t)
+        # GEGLU feed-forward
+        y = ops.layer_norm(t, *self.ln[2])
+        f = ops.linear(y, self.ff1)
+        t = ops.linear(f, self.ff2, residual=t)
+        return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x)
+
+
+class EncoderHalf:
+    """conv_in + time embedding + down blocks + mid block shared by UNet2DConditionModel and ControlNetModel."""
+
+    def __init__(self, sd, cfg, device, extra_resnets=()):
+        self.cfg = cfg
+        boc, g = cfg["block_out_channels"], cfg["groups"]
+        self.conv_in = PackedConv(sd["conv_in.weight"], sd["conv_in.bias"], device)
+        self.down = []
+        res_prefixes = []
+        for i in range(len(boc)):
+            blk = dict(resnets=[], attns=[], down=None)
+            for j in range(cfg["layers_per_block"]):
+                p = f"down_blocks.{i}.resnets.{j}."
+                res_prefixes.append(p)
+                blk["resnets"].append(ResnetBlock(sd, p, device, g, 1e-5))
+                blk["attns"].append(TransformerBlock(sd, f"down_blocks.{i}.attentions.{j}.", device, cfg["num_heads"], g)
+                                    if cfg["down_cross"][i] else None)
+            if i != len(boc) - 1:
+                k = f"down_blocks.{i}.downsamplers.0.conv"
+                blk["down"] = PackedConv(sd[k + ".weight"], sd[k + ".bias"], device)
+            self.down.append(blk)
+        self.mid_res0 = ResnetBlock(sd, "mid_block.resnets.0.", device, g, 1e-5)
+        self.mid_attn = TransformerBlock(sd, "mid_block.attentions.0.", device, cfg["num_heads"], g)
+        self.mid_res1 = ResnetBlock(sd, "mid_block.resnets.1.", device, g, 1e-5)
+        res_prefixes += ["mid_block.resnets.0.", "mid_block.resnets.1."] + list(extra_resnets)
+        self.temb = TimeEmbedding(sd, device, boc[0], res_prefixes)
+
+    def transformers(self):
+        for blk in self.down:
+            for a in blk["attns"]:
+                if a is not None:
+                    yield a
+        yield self.mid_attn
+
+    def run_down(self, sample, temb, after_block=None):
+        res = [sample]
+        for i, blk in enumerate(self.down):
+            for r, a in zip(blk["resnets"], blk["attns"]):
+                sample = r(sample, temb)
+                if a is not None:
+                    sample = a(sample)
+                res.append(sample)
+            if blk["down"] is not None:
+                sample = ops.conv(sample, blk["down"], stride=2)
+                res.append(sample)
+            if after_block is not None:
+                sample = after_block(i, sample)
+        return sample, res
+
+    def run_mid(self, sample, temb):
+        sample = self.mid_res0(sample, temb)
+        sample = self.mid_attn(sample)
+        return self.mid_res1(sample, temb)

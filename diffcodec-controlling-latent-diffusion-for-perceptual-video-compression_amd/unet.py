@@ -1,0 +1,118 @@
+"""`UNet2DConditionModel` operator of the decode path (call site pipeline.py:358-367), MI355X-native.
+
+Same call surface as the diffusers module the reference passes to its pipeline:
+    unet(sample, timestep, encoder_hidden_states=..., timestep_cond=None, cross_attention_kwargs=None,
+         down_block_additional_residuals=[12 tensors], mid_block_additional_residual=tensor, return_dict=False)[0]
+plus `.config.in_channels`, `.config.time_cond_proj_dim`, `.dtype`, `.device`.
+Tensors cross this boundary as logical NCHW torch tensors; inside, everything is NHWC bf16 and every op is a
+C-ABI launch (`ops`)."""
+from types import SimpleNamespace
+
+import torch
+
+from . import ops, weights
+from .blocks import EncoderHalf, ResnetBlock, TransformerBlock
+from .ops import PackedConv
+
+
+def to_nhwc_bf16(x):
+    """boundary conversion: logical NCHW tensor (any float dtype / memory format) -> NHWC bf16 device tensor."""
+    if x.dtype == torch.bfloat16 and x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1)
+    return ops.nchw_f32_to_nhwc_bf16(x.float().contiguous())
+
+
+def as_nchw(x_nhwc):
+    """zero-copy logical-NCHW view (channels_last memory) of an NHWC tensor."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+class HipUNet2DConditionModel:
+    def __init__(self, state_dict, config=None, device="cuda"):
+        cfg = dict(weights.SD15_UNET_CONFIG if config is None else config)
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self.config = SimpleNamespace(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+                                      time_cond_proj_dim=cfg.get("time_cond_proj_dim"),
+                                      block_out_channels=cfg["block_out_channels"], cross_attention_dim=cfg["cross_attention_dim"])
+        sd, g, boc = state_dict, cfg["groups"], cfg["block_out_channels"]
+        nb = len(boc)
+        up_res = [f"up_blocks.{i}.resnets.{j}." for i in range(nb) for j in range(cfg["layers_per_block"] + 1)]
+        self.enc = EncoderHalf(sd, cfg, device, extra_resnets=up_res)
+        self.up = []
+        for i in range(nb):
+            cross = cfg["down_cross"][nb - 1 - i]
+            blk = dict(resnets=[], attns=[], up=None)
+            for j in range(cfg["layers_per_block"] + 1):
+                blk["resnets"].append(ResnetBlock(sd, f"up_blocks.{i}.resnets.{j}.", device, g, 1e-5))
+                blk["attns"].append(TransformerBlock(sd, f"up_blocks.{i}.attentions.{j}.", device, cfg["num_heads"], g) if cross else None)
+            if i != nb - 1:
+                k = f"up_blocks.{i}.upsamplers.0.conv"
+                blk["up"] = PackedConv(sd[k + ".weight"], sd[k + ".bias"], device)
+            self.up.append(blk)
+        self.norm_out = (sd["conv_norm_out.weight"].float().to(device), sd["conv_norm_out.bias"].float().to(device))
+        self.conv_out = PackedConv(sd["conv_out.weight"], sd["conv_out.bias"], device)
+        self._ctx_key = None
+
+    # ---- reference-compatible niceties
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def transformers(self):
+        yield from self.enc.transformers()
+        for blk in self.up:
+            for a in blk["attns"]:
+                if a is not None:
+                    yield a
+
+    def set_context(self, ctx):
+        """Cache the cross-attention K/V of a text embedding [B,77,768] (identity-keyed; step-invariant)."""
+        key = (ctx.data_ptr(), tuple(ctx.shape), ctx._version)
+        if key == self._ctx_key:
+            return
+        cb = ctx.to(device=self.device, dtype=torch.bfloat16).contiguous()
+        for t in self.transformers():
+            t.set_context(cb)
+        self._ctx_key = key
+        self._ctx_keepalive = ctx
+
+    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None):
+        """x NHWC bf16 [n,h,w,4]; t_dev fp32 device scalar (or table indexed by step_dev); residuals NHWC bf16.
+        Returns eps NHWC fp32 [n,h,w,4]."""
+        enc = self.enc
+        temb = enc.temb(t_dev, x.shape[0], step_dev)
+        sample = ops.conv(x, enc.conv_in)
+        sample, res = enc.run_down(sample, temb)
+        if down_res is not None:
+            assert len(down_res) == len(res)
+            res = [ops.add_bf16(a, b) for a, b in zip(res, down_res)]          # pipeline.py:364 residual injection
+        sample = enc.run_mid(sample, temb)
+        if mid_res is not None:
+            sample = ops.add_bf16(sample, mid_res)
+        for blk in self.up:
+            for r, a in zip(blk["resnets"], blk["attns"]):
+                sample = r(sample, temb, x2=res.pop())                         # cat[sample, skip] read in place
+                if a is not None:
+                    sample = a(sample)
+            if blk["up"] is not None:
+                sample = ops.conv(sample, blk["up"], upsample=True)            # nearest-2x fused into the conv load
+        ab = ops.group_norm_ab(sample, self.norm_out[0], self.norm_out[1], self.cfg["groups"], 1e-5)
+        return ops.conv(sample, self.conv_out, gn_ab=ab, gn_silu=True, out_f32=True)
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict=False, **kw):
+        if timestep_cond is not None or cross_attention_kwargs:
+            raise NotImplementedError("timestep_cond / cross_attention_kwargs are None for SD-1.5 (pipeline.py:281-286)")
+        self.set_context(encoder_hidden_states)
+        t_dev = torch.as_tensor(timestep).to(device=self.device, dtype=torch.float32).reshape(-1)[:1].contiguous()
+        x = to_nhwc_bf16(sample.to(self.device))
+        down = None if down_block_additional_residuals is None else [to_nhwc_bf16(d) for d in down_block_additional_residuals]
+        mid = None if mid_block_additional_residual is None else to_nhwc_bf16(mid_block_additional_residual)
+        eps = as_nchw(self.forward_nhwc(x, t_dev, down, mid))
+        return (eps,) if not return_dict else SimpleNamespace(sample=eps)
+
+    __call__ = forward

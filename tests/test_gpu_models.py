@@ -1,0 +1,151 @@
+"""GPU parity of the assembled operators (ControlNet pyramid, DualFlowControlNet, UNet, VAE, the full sampling loop)
+against the CPU oracle on identical seeded weights and inputs.  Device path is bf16 with fp32 accumulation; the
+oracle is fp32, so the bar is a relative-L2 / PSNR tolerance stated per test (north_star: "within a stated fp16
+tolerance").  Reduced-width SD-1.5 topology keeps the oracle at seconds; one test runs the true SD-1.5 widths."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def small():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import selftest as T
+    pipe, sds = T.build_small_pipeline()
+    return T, pipe, sds
+
+
+def _inputs(T, b=1, size=256):
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    cond, flow = synth_controls(b, size)
+    pe, npe = synth_text(b, dim=T.SMALL_UNET["cross_attention_dim"])
+    return cond, flow, pe, npe, synth_latents(b, size)
+
+
+def test_control_pyramid_fp32(small):
+    """extractors.py:264-316 on the device (fp32) vs the golden-pinned oracle restatement."""
+    T, pipe, (usd, csd, vsd) = small
+    from oracle import control_ref as C
+    cond, flow, *_ = _inputs(T, b=2)
+    ref = C.bi_dir_feature_extractor(csd, "feature_extractor.", cond, flow)
+    out = pipe.controlnet.compute_pyramid(cond, flow)
+    for o, r in zip(out, ref):
+        assert o.shape == r.shape
+        # fp32 both sides; differences: atomic order + the few pixels whose occlusion test sits at the 0.3 threshold
+        bad = ((o.cpu() - r).abs() > 1e-3 + 1e-3 * r.abs()).float().mean().item()
+        assert bad < 5e-3, bad
+
+
+def test_extractor_golden_512(golden_dir):
+    """Device pyramid vs the golden captured from the imported reference (512x512, narrow channels)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import numpy as np
+    from diffcodec_amd.controlnet import BiDirFeatureExtractor
+    from diffcodec_amd.synthetic import synth_controls
+    z = np.load(os.path.join(golden_dir, "control_extractor512.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    fe = BiDirFeatureExtractor(sd, "", DEV)
+    cond, flow = synth_controls(1, 512, seed=1234)
+    outs = fe(cond.to(DEV), flow.to(DEV))
+    for i, o in enumerate(outs):
+        r = torch.from_numpy(z[f"p{i}"])
+        bad = ((o.cpu() - r).abs() > 1e-3 + 1e-3 * r.abs()).float().mean().item()
+        assert bad < 5e-3, (i, bad)
+
+
+def test_controlnet_and_unet_forward(small):
+    T, pipe, (usd, csd, vsd) = small
+    from oracle import sd15_ref as M
+    cond, flow, pe, npe, lat = _inputs(T)
+    ctx = torch.cat([npe, pe], 0)
+    x = torch.cat([lat, lat], 0)
+    cc, fc = torch.cat([cond, cond], 0), torch.cat([flow, flow], 0)
+    rd, rm = M.dualflow_controlnet_forward(csd, T.SMALL_UNET, x, 801, ctx, cc, fc, 1.7)
+    down, mid = pipe.controlnet(sample=x.to(DEV), timestep=801, encoder_hidden_states=ctx.to(DEV), controlnet_cond=cc.to(DEV),
+                                flow_cond=fc.to(DEV), conditioning_scale=1.7, guess_mode=False, return_dict=False)
+    assert len(down) == 12
+    for d, r in zip(down + [mid], rd + [rm]):
+        assert tuple(d.shape) == tuple(r.shape)
+        assert T.rel_l2(d.float().cpu(), r) < 4e-2
+    re = M.unet_forward(usd, T.SMALL_UNET, x, 801, ctx, rd, rm)
+    eps = pipe.unet(x.to(DEV), 801, encoder_hidden_states=ctx.to(DEV), down_block_additional_residuals=[r.to(DEV) for r in rd],
+                    mid_block_additional_residual=rm.to(DEV), return_dict=False)[0]
+    assert tuple(eps.shape) == tuple(re.shape)
+    assert T.rel_l2(eps.float().cpu(), re) < 4e-2
+
+
+def test_vae_decode_encode(small):
+    T, pipe, (usd, csd, vsd) = small
+    from oracle import sd15_ref as M
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 4, 32, 32, generator=g)
+    ref = M.vae_decode(vsd, T.SMALL_VAE, z)
+    img = pipe.vae.decode(z.to(DEV), return_dict=False)[0]
+    assert T.rel_l2(img.float().cpu(), ref) < 4e-2
+    x = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    mean, logvar = M.vae_encode_moments(vsd, T.SMALL_VAE, x)
+    dist = pipe.vae.encode(x.to(DEV)).latent_dist
+    mom = dist.moments_nhwc.float().cpu().permute(0, 3, 1, 2)
+    assert T.rel_l2(mom[:, :4], mean) < 5e-2
+    lat = dist.mode().cpu()
+    assert T.rel_l2(lat, mean) < 5e-2
+
+
+def test_pipeline_fused_generic_and_graph_agree_with_oracle(small):
+    """4-step DDIM decode of one 256x256 frame (config-1 plumbing): fused loop, generic loop and hipGraph replay
+    all against the oracle's fp32 loop."""
+    T, pipe, (usd, csd, vsd) = small
+    from oracle import pipeline_ref as R
+    cond, flow, pe, npe, lat = _inputs(T)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=4, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+    ref_img, ref_lat = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, num_inference_steps=4,
+                                      guidance_scale=4.5, controlnet_conditioning_scale=1.7, return_latents=True)
+    img = pipe(**kw).images.float().cpu()
+    lat_f = pipe(**dict(kw, output_type="latent")).images.float().cpu()
+    assert T.rel_l2(lat_f, ref_lat) < 5e-2
+    assert T.psnr(img, ref_img) > 30.0
+    # generic loop (callback forces it) == fused loop up to bf16 round-trips of the residual tensors
+    seen = []
+    img_g = pipe(**kw, callback_on_step_end=lambda p, i, t, d: (seen.append(int(t)), d)[1]).images.float().cpu()
+    assert seen == [751, 501, 251, 1]
+    assert T.psnr(img_g, ref_img) > 30.0
+    # hipGraph replay == eager fused
+    pipe.enable_hip_graphs(True)
+    try:
+        img_h = pipe(**kw).images.float().cpu()
+        img_h2 = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.enable_hip_graphs(False)
+    assert T.psnr(img_h, img) > 45.0 and T.psnr(img_h2, img) > 45.0
+
+
+def test_pipeline_errors_and_batch(small):
+    T, pipe, _ = small
+    cond, flow, pe, npe, lat = _inputs(T, b=2)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, controlnet_cond=None, flow_cond=flow)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, controlnet_cond=cond[:, :5], flow_cond=flow)
+    with pytest.raises(ValueError):
+        pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=torch.cat([cond, cond[:1]]), flow_cond=torch.cat([flow, flow[:1]]))
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+               num_inference_steps=2, guidance_scale=4.5, output_type="np")
+    assert out.images.shape == (2, 256, 256, 3)
+    # frames are independent units: batch of 2 == two single-frame calls (sharding premise)
+    one = pipe(prompt_embeds=pe[1:], negative_prompt_embeds=npe[1:], controlnet_cond=cond[1:], flow_cond=flow[1:], latents=lat[1:],
+               num_inference_steps=2, guidance_scale=4.5, output_type="np")
+    assert T.psnr(torch.from_numpy(one.images[0]), torch.from_numpy(out.images[1])) > 40.0
+
+
+def test_smoke_entry():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import __graft_entry__ as g
+    g.smoke()
