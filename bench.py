@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — decoded frames/s of the DiffCodec decode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--no-graphs]
+
+A "step" is one pass of the hot path over one batch of F synthetic 512x512 inter frames resident in HBM:
+control pyramid + FDN gamma/beta (once per frame), 20 DDIM steps of {DualFlowControlNet, UNet} with CFG
+(model batch 2F), CFG+DDIM update, VAE decode, postprocess.  SD-1.5 topology, random-init weights in the
+diffusers key layout (no checkpoints are reachable offline), bf16 compute with fp32 accumulation.
+N > 1: one process per GPU (torch.distributed / RCCL); frames are sharded across ranks with no data-path
+collective; rank 0 synthesises the weights and broadcasts the packed tensors once (outside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+STEPS_DDIM = 20
+SIZE = 512
+# algorithmic work per decoded frame (CFG on, step-invariant parts hoisted): TFLOP
+TFLOP_PER_FRAME = (20 * 2 * (803.3 + 268.6) + 30.2 + 19.9 + 2514.5) / 1000.0
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_pipeline(rank, device):
+    from diffcodec_amd import weights as W
+    from diffcodec_amd.controlnet import HipDualFlowControlNet
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline
+    from diffcodec_amd.scheduler import DDIMScheduler
+    from diffcodec_amd.unet import HipUNet2DConditionModel
+    from diffcodec_amd.vae import HipAutoencoderKL
+    t0 = time.time()
+    specs = (W.unet_spec(), W.controlnet_spec(), W.vae_spec())
+    if rank == 0:
+        sds = [W.synthesize(s, seed=i) for i, s in enumerate(specs)]
+    else:   # shapes only; the packed device tensors are overwritten by the broadcast from rank 0
+        sds = [{k: torch.empty(shape) for k, (_, shape) in s.items()} for s in specs]
+    log(f"[rank {rank}] state dicts ready in {time.time() - t0:.1f}s")
+    unet = HipUNet2DConditionModel(sds[0], W.SD15_UNET_CONFIG, device)
+    cn = HipDualFlowControlNet(sds[1], W.SD15_UNET_CONFIG, device)
+    vae = HipAutoencoderKL(sds[2], W.SD15_VAE_CONFIG, device)
+    pipe = StableDiffusionDualFlowControlNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, controlnet=cn,
+                                                     scheduler=DDIMScheduler(), safety_checker=None, feature_extractor=None)
+    log(f"[rank {rank}] operators packed + uploaded in {time.time() - t0:.1f}s")
+    return pipe, (sds if rank == 0 else None)
+
+
+def cpu_baseline(sds, threads):
+    """Oracle (CPU restatement, kind 'port') on the host cores, bounded sample of the same workload:
+    ONE DDIM step with CFG (ControlNet + UNet at model batch 2, 512x512) + the control pyramid + VAE decode,
+    extrapolated to 20 steps.  Reported next to the GPU number; never part of `value`."""
+    from diffcodec_amd import weights as W
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    from oracle import control_ref as C
+    from oracle import sd15_ref as M
+    torch.set_num_threads(threads)
+    usd, csd, vsd = sds
+    cond, flow = synth_controls(1, SIZE)
+    pe, npe = synth_text(1)
+    lat = synth_latents(1, SIZE)
+    ctx = torch.cat([npe, pe], 0)
+    x = torch.cat([lat, lat], 0)
+    with torch.no_grad():
+        t0 = time.time()
+        pyr = C.bi_dir_feature_extractor(csd, "feature_extractor.", cond, flow)
+        t_pyr = time.time() - t0
+        t0 = time.time()
+        p2 = [torch.cat([q, q], 0) for q in pyr]
+        down, mid = M.dualflow_controlnet_forward(csd, W.SD15_UNET_CONFIG, x, 951, ctx, None, None, 1.7, pyramid=p2)
+        eps = M.unet_forward(usd, W.SD15_UNET_CONFIG, x, 951, ctx, down, mid)
+        t_step = time.time() - t0
+        t0 = time.time()
+        M.vae_decode(vsd, W.SD15_VAE_CONFIG, lat / 0.18215)
+        t_vae = time.time() - t0
+    assert torch.isfinite(eps).all()
+    frame_s = t_pyr + STEPS_DDIM * t_step + t_vae
+    return dict(value=1.0 / frame_s, unit="frames/s", cores=threads, kind="port",
+                sample=f"1 of 20 DDIM steps (CFG, ControlNet+UNet, batch 2) {t_step:.2f}s + pyramid {t_pyr:.2f}s + VAE decode "
+                       f"{t_vae:.2f}s at 512x512 fp32, extrapolated x20 steps -> {frame_s:.1f}s/frame")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=1, help="inter frames decoded per step per GPU")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from diffcodec_amd import ops, sharding
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    rank, local, world = sharding.init_from_env()
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    pipe, sds = build_pipeline(rank, device)
+    if world > 1:
+        t0 = time.time()
+        nbytes = sharding.broadcast_params(sharding.module_param_tensors(pipe.unet, pipe.controlnet, pipe.vae))
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s")
+    pipe.enable_hip_graphs(not args.no_graphs)
+
+    F = args.frames
+    # two alternating input sets (distinct tensors) so that no per-call cache can carry work across steps
+    sets = []
+    for s in range(2):
+        cond, flow = synth_controls(F, SIZE, seed=1234 + 17 * s + 1000 * rank)
+        pe, npe = synth_text(F, seed=77 + s)
+        lat = synth_latents(F, SIZE, seed=4321 + s + 1000 * rank)
+        sets.append(dict(controlnet_cond=cond.to(device), flow_cond=flow.to(device), prompt_embeds=pe.to(device),
+                         negative_prompt_embeds=npe.to(device), latents=lat.to(device)))
+    kw = dict(num_inference_steps=STEPS_DDIM, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+
+    def one_step(i):
+        return pipe(**sets[i % 2], **kw).images
+
+    for i in range(args.warmup):
+        out = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all() and out.shape == (F, 3, SIZE, SIZE)
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+
+    # ---- roofline leg (after the timed region): HIP events around every MFMA implicit-GEMM launch of one eager frame
+    roof = None
+    if rank == 0:
+        pipe.enable_hip_graphs(False)
+        ops.PROFILE = []
+        one_step(0)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+        tot_fl = sum(f for _, _, f, _ in recs)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                    traffic=None, kernel="igemm_kernel (dc_conv_igemm_bf16)", launches=len(recs),
+                    avg_launch_us=round(tot_ms * 1e3 / max(1, len(recs)), 2),
+                    note="sum of algorithmic 2*M*N*K over the igemm launches of one frame / sum of their HIP-event durations")
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sds, threads=os.cpu_count() or 1)
+
+    if rank == 0:
+        frames = F * world * args.steps
+        fps = frames / dt
+        line = {
+            "metric": "decoded frames/sec @ 512x512, 20-step DDIM, GOP-12",
+            "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"512x512 inter frames, {F} per step per GPU, 20-step DDIM, CFG 4.5 (model batch {2 * F}), "
+                                   f"control scale 1.7, SD-1.5 + DualFlowControlNet + VAE decode, random-init weights",
+                       "frames_per_step_per_gpu": F, "hip_graphs": not args.no_graphs, "parallelism": f"frame-shard x{world}"},
+            "frame_tflop_algorithmic": round(TFLOP_PER_FRAME, 2),
+            "frame_mfma_frac": round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ from .lib import ConvDesc
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+PROFILE = None      # list collecting (start_event, end_event, flops, label) per igemm launch when set by bench.py
 
 
 def _stream():
@@ -143,7 +144,14 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
                  Ho=ho, Wo=wo, gn_silu=int(gn_silu), epilogue=1 if pc.geglu else 0, out_f32=int(out_f32),
                  out_scale=float(out_scale), splitk=int(splitk), gn_batch=0 if gn_ab is None else gn_ab.shape[0],
                  act=int(act), row_add_stride=int(ras))
-    lib.call("dc_conv_igemm_bf16", d, _stream())
+    if PROFILE is None:
+        lib.call("dc_conv_igemm_bf16", d, _stream())
+    else:   # bench.py roofline leg: HIP events on the launch stream around this launch (never active in the timed region)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call("dc_conv_igemm_bf16", d, _stream())
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * m * pc.cout * pc.cin * k * k, f"{k}x{k} M={m} N={pc.cout} K={pc.cin * k * k} splitk={splitk}"))
     return out
 
 
