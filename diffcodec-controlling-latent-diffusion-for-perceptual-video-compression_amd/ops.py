@@ -146,12 +146,13 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
                  act=int(act), row_add_stride=int(ras))
     if PROFILE is None:
         lib.call("dc_conv_igemm_bf16", d, _stream())
-    else:   # bench.py roofline leg: HIP events on the launch stream around this launch (never active in the timed region)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    else:   # bench.py roofline leg (never active in the timed region): remember how to relaunch this exact launch
         lib.call("dc_conv_igemm_bf16", d, _stream())
-        e1.record()
-        PROFILE.append((e0, e1, 2.0 * m * pc.cout * pc.cin * k * k, f"{k}x{k} M={m} N={pc.cout} K={pc.cin * k * k} splitk={splitk}"))
+        keep = (x1, x2, pc, gn_ab, row_add, residual, out, ws)
+        PROFILE.append((2.0 * m * pc.cout * pc.cin * k * k,
+                        f"{k}x{k} s{stride} up{int(upsample)} M={m} N={pc.cout} K={pc.cin * k * k} gn={int(gn_ab is not None)} "
+                        f"geglu={int(pc.geglu)} splitk={splitk}",
+                        lambda d=d, keep=keep: lib.call("dc_conv_igemm_bf16", d, _stream())))
     return out
 
 
