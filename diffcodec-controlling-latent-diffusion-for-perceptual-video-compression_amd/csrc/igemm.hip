@@ -14,6 +14,10 @@
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
 
+// conv3x3_tile.hip: LDS-staged 2D-tile kernel for 3x3 stride-1 convs with tile-aligned outputs
+int dc_conv3x3_tile_supported(const dc_conv_desc& d);
+int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st);
+
 namespace {
 
 constexpr int BK = 64;
@@ -87,8 +91,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
 
     u32x4 ra[PA], rb[PB];
     unsigned va = 0;                     // validity bits of the staged A rows
-    f32x4 gab[4];                        // GN (scale,shift) of this thread's 8 channels for sample a_n[0]
     int cur_c = 0;
+    int a_nb[PA];                        // gn_ab row of each staged A row's sample
+#pragma unroll
+    for (int i = 0; i < PA; ++i) a_nb[i] = GN ? a_n[i] % d.gn_batch : 0;
 
     auto issue_loads = [&](int kt) {
         const int tap = KS3 ? kt / nkc : 0;
@@ -127,11 +133,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
             }
             ra[i] = v;
         }
-        if (GN) {
-            const float* __restrict__ abp = d.gn_ab + ((long long)(a_n[0] % d.gn_batch) * Cin + c) * 2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gab[j] = *(const f32x4*)(abp + 4 * j);
-        }
         const long long wk = (long long)tap * Cin + cc * 64 + q * 8;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -150,12 +151,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
             u32x4 v = ra[i];
             if (GN) {
                 if (va & (1u << i)) {
-                    f32x4 g[4] = {gab[0], gab[1], gab[2], gab[3]};
-                    if (a_n[i] != a_n[0]) {          // tile straddles two samples (small feature maps)
-                        const float* __restrict__ abp = d.gn_ab + ((long long)(a_n[i] % d.gn_batch) * Cin + cur_c) * 2;
+                    // (scale, shift) of this row's sample: 64 B, L1-resident (shared by the 32 rows of a pass)
+                    const float* __restrict__ abp = d.gn_ab + ((long long)a_nb[i] * Cin + cur_c) * 2;
+                    f32x4 g[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) g[j] = *(const f32x4*)(abp + 4 * j);
-                    }
+                    for (int j = 0; j < 4; ++j) g[j] = *(const f32x4*)(abp + 4 * j);
                     uint32_t o[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -399,7 +399,8 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     const int bn = n160 ? 160 : 128;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * d.splitk;
     int rc;
-    if (big_tiles >= 512) rc = n160 ? launch_cfg<2, 2, 4, 5>(d, st) : launch_cfg<2, 2, 4, 4>(d, st);
+    if (dc_conv3x3_tile_supported(d)) rc = dc_conv3x3_tile_launch(d, st);
+    else if (big_tiles >= 512) rc = n160 ? launch_cfg<2, 2, 4, 5>(d, st) : launch_cfg<2, 2, 4, 4>(d, st);
     else rc = n160 ? launch_cfg<2, 2, 2, 5>(d, st) : launch_cfg<2, 2, 2, 4>(d, st);
     if (rc != DC_OK) return rc;
     if (d.splitk > 1) {
