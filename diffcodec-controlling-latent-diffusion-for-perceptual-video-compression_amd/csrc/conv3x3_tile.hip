@@ -40,7 +40,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 
     const int Cin = d.C1 + d.C2;
     const int nchunks = Cin >> 6;
-    const int tiles_x = d.Wo >> 4, tiles_y = d.Ho / TH;
+    // narrow maps (Wo == 8): the 16 lanes of an MFMA row cover 2 image rows of 8 pixels (sh = 1)
+    const int sh = d.Wo < 16 ? 1 : 0;
+    const int TW = 16 >> sh;
+    const int tiles_x = d.Wo / TW, tiles_y = d.Ho / (TH << sh);
     const int n_tiles = (d.Cout + BN - 1) / BN;
     const int m_tiles = d.N * tiles_y * tiles_x;
     const int nblk = n_tiles * m_tiles;
@@ -53,7 +56,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     int tile_m = bid / n_tiles;
     const int n_img = tile_m / (tiles_y * tiles_x);
     tile_m -= n_img * tiles_y * tiles_x;
-    const int oy0 = (tile_m / tiles_x) * TH, ox0 = (tile_m % tiles_x) * 16;
+    const int oy0 = (tile_m / tiles_x) * (TH << sh), ox0 = (tile_m % tiles_x) * TW;
+    const int fdx = fr & (TW - 1), fdy = fr >> (4 - sh);
     const int n0 = tile_n * BN;
 
     int c_begin = 0, c_end = nchunks;
@@ -66,8 +70,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 
     // ---- halo geometry (input coordinates).  upsample: output tile lives on the 2x grid, halo on the input grid
     const int up = d.upsample;
-    const int HWd = up ? 10 : 18;
-    const int HHt = up ? TH / 2 + 2 : TH + 2;
+    const int HWd = up ? 10 : TW + 2;
+    const int HHt = up ? TH / 2 + 2 : (TH << sh) + 2;
     const int iy0 = up ? (oy0 >> 1) - 1 : oy0 - 1;
     const int ix0 = up ? (ox0 >> 1) - 1 : ox0 - 1;
     int h_pix[NHU];                                   // input pixel index of each staged unit, -1 = zero padding, -2 = unused
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int ty = wm * TM + tm;
-            prow[tm] = up ? (((ty + ky - 1) >> 1) + 1) * 10 + ((fr + kx - 1) >> 1) + 1 : (ty + ky) * 18 + fr + kx;
+            prow[tm] = up ? (((ty + ky - 1) >> 1) + 1) * 10 + ((fr + kx - 1) >> 1) + 1
+                          : ((ty << sh) + fdy + ky) * HWd + fdx + kx;
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3]
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int oy = oy0 + wm * TM + tm, ox = ox0 + fr;
+        const int oy = oy0 + ((wm * TM + tm) << sh) + fdy, ox = ox0 + fdx;
         const long long m = ((long long)n_img * d.Ho + oy) * d.Wo + ox;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -259,7 +264,8 @@ template <int TM, int TN>
 int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
-    const int nblk = d.N * (d.Ho / TH) * (d.Wo / 16) * dc_cdiv(d.Cout, BN);
+    const int sh = d.Wo < 16 ? 1 : 0;
+    const int nblk = d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh)) * dc_cdiv(d.Cout, BN);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
     const size_t lds = (TH + 2) * 18 * 128 + 2 * BN * 128;
 #define DC_TILE_LAUNCH(GN)                                                                                      \
@@ -283,7 +289,9 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
 // Returns 1 if the halo-tile kernel can take this descriptor (3x3, stride 1, pad 1, tile-aligned output).
 int dc_conv3x3_tile_supported(const dc_conv_desc& d)
 {
-    return d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.epilogue == 0 && (d.Wo % 16) == 0 && (d.Ho % 4) == 0;
+    if (!(d.ksize == 3 && d.stride == 1 && d.pad == 1 && d.epilogue == 0)) return 0;
+    if (d.Wo == 8) return !d.upsample && (d.Ho % 8) == 0;       // narrow: tile = 8 rows x 8 cols (TM = 2)
+    return (d.Wo % 16) == 0 && (d.Ho % 4) == 0;
 }
 
 // Called by dc_conv_igemm_bf16 after validation (workspace already zeroed for splitk > 1).
@@ -292,6 +300,6 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     const bool n160 = d.Cout % 160 == 0;
     const int bn = n160 ? 160 : 128;
     const long long big = (long long)d.N * (d.Ho / 8) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
-    if ((d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5>(d, st) : launch_tile<4, 4>(d, st);
+    if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5>(d, st) : launch_tile<4, 4>(d, st);
     return n160 ? launch_tile<2, 5>(d, st) : launch_tile<2, 4>(d, st);
 }

@@ -8,18 +8,17 @@
 
 namespace {
 
-// Per-(n,c) sum and sum of squares.  grid = (pixel chunks, N); each thread owns one 8-channel vector column and
-// strides over pixels; partials meet in LDS, then one global atomic pair per channel per workgroup.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums,
-                                                       long long HW, int C, int pix_per_block)
+// Per-(chunk, n, c) partial sum and sum of squares — no atomics, no memset: grid = (pixel chunks, N); each thread owns
+// one 8-channel vector column and strides over the chunk's pixels; the pixel-parallel partials are combined through LDS
+// and each workgroup writes its own [C][2] slab.  The finalize kernel sums the slabs.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                       long long HW, int C, int pix_per_block, int N)
 {
-    extern __shared__ float red[];                 // [C][2]
+    extern __shared__ float red[];                 // [ppb][C][2]
     const int nv = C >> 3;
     const int n = blockIdx.y;
     const long long p_begin = (long long)blockIdx.x * pix_per_block;
     const long long p_end = min(HW, p_begin + pix_per_block);
-    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
     const int tpp = min(nv, 256);                  // threads per pixel
     const int ppb = 256 / tpp;                     // pixels in flight
     const int vl = threadIdx.x % tpp, pl = threadIdx.x / tpp;
@@ -40,20 +39,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
                     ss[2 * j + 1] += hi * hi;
                 }
             }
+            float* r = red + ((long long)pl * C + v * 8) * 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                atomicAdd(&red[(v * 8 + j) * 2], s[j]);
-                atomicAdd(&red[(v * 8 + j) * 2 + 1], ss[j]);
+                r[2 * j] = s[j];
+                r[2 * j + 1] = ss[j];
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[(long long)n * C * 2 + i], red[i]);
+    float* out = part + ((long long)blockIdx.x * N + n) * C * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float a = 0.f;
+        for (int k = 0; k < ppb; ++k) a += red[(long long)k * C * 2 + i];
+        out[i] = a;
+    }
 }
 
-// One thread per (n, c): sum the group's channel sums (<= a few dozen), emit scale/shift.
-__global__ void gn_finalize_kernel(const float* __restrict__ s1, int C1, const float* __restrict__ s2, int C2,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+// One thread per (n, c): sum the group's channel sums over all chunk slabs, emit scale/shift.
+__global__ void gn_finalize_kernel(const float* __restrict__ s1, int C1, int chunks1, const float* __restrict__ s2, int C2,
+                                   int chunks2, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ ab, int N, int groups, float inv_count, float eps)
 {
     const int C = C1 + C2;
@@ -64,9 +69,14 @@ __global__ void gn_finalize_kernel(const float* __restrict__ s1, int C1, const f
     const int g0 = (c / cpg) * cpg;
     float s = 0.f, ss = 0.f;
     for (int k = g0; k < g0 + cpg; ++k) {
-        const float* p = k < C1 ? s1 + ((long long)n * C1 + k) * 2 : s2 + ((long long)n * C2 + (k - C1)) * 2;
-        s += p[0];
-        ss += p[1];
+        const bool first = k < C1;
+        const float* p = first ? s1 + ((long long)n * C1 + k) * 2 : s2 + ((long long)n * C2 + (k - C1)) * 2;
+        const long long stride = (long long)N * (first ? C1 : C2) * 2;
+        const int chunks = first ? chunks1 : chunks2;
+        for (int ch = 0; ch < chunks; ++ch) {
+            s += p[ch * stride];
+            ss += p[ch * stride + 1];
+        }
     }
     const float mean = s * inv_count;
     const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
@@ -188,29 +198,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 }  // namespace
 
-extern "C" int dc_gn_stats_nhwc_bf16(const void* x, float* sums, int N, long long HW, int C, void* stream)
+// chunk count used by both the stats launcher and its callers (partials buffer = chunks * N * C * 2 floats)
+extern "C" int dc_gn_stats_chunks(long long HW, int C)
 {
-    if (!x || !sums || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 8192) return DC_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, (size_t)N * C * 2 * sizeof(float), st) != hipSuccess) return DC_ERR_LAUNCH;
-    // up to 512 pixel chunks per sample: enough workgroups to stream at HBM rate, few enough final atomics
-    long long chunks = HW / 128;
+    const int nv = C >> 3;
+    const int tpp = nv < 256 ? nv : 256;
+    const int ppb = 256 / tpp;                      // pixels processed concurrently by one workgroup
+    long long chunks = HW / (8LL * ppb);            // >= 8 pixels per pixel-lane
     if (chunks < 1) chunks = 1;
-    if (chunks > 512) chunks = 512;
-    const int ppb = (int)((HW + chunks - 1) / chunks);
-    const dim3 grid(dc_cdiv(HW, ppb), N);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)C * 2 * sizeof(float), st, (const bf16_t*)x, sums, HW, C, ppb);
+    if (chunks > 64) chunks = 64;
+    return (int)chunks;
+}
+
+extern "C" int dc_gn_stats_nhwc_bf16(const void* x, float* partials, int N, long long HW, int C, void* stream)
+{
+    if (!x || !partials || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 8192) return DC_ERR_INVALID;
+    const int chunks = dc_gn_stats_chunks(HW, C);
+    const int ppb_pix = (int)((HW + chunks - 1) / chunks);
+    const int nv = C >> 3, tpp = nv < 256 ? nv : 256, ppb = 256 / tpp;
+    const dim3 grid(chunks, N);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), (size_t)ppb * C * 2 * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, partials, HW, C, ppb_pix, N);
     return dc_launch_status();
 }
 
-extern "C" int dc_gn_finalize(const float* sums1, int C1, const float* sums2, int C2, const float* gamma,
-                              const float* beta, float* ab, int N, int groups, long long HW, float eps, void* stream)
+extern "C" int dc_gn_finalize(const float* sums1, int C1, int chunks1, const float* sums2, int C2, int chunks2,
+                              const float* gamma, const float* beta, float* ab, int N, int groups, long long HW, float eps,
+                              void* stream)
 {
     const int C = C1 + C2;
-    if (!sums1 || !ab || N <= 0 || groups <= 0 || C <= 0 || C % groups || (C2 && !sums2)) return DC_ERR_INVALID;
+    if (!sums1 || !ab || N <= 0 || groups <= 0 || C <= 0 || C % groups || (C2 && !sums2) || chunks1 <= 0) return DC_ERR_INVALID;
     const float inv_count = 1.0f / ((float)HW * (float)(C / groups));
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(dc_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       sums1, C1, sums2, C2, gamma, beta, ab, N, groups, inv_count, eps);
+                       sums1, C1, chunks1, sums2, C2, chunks2, gamma, beta, ab, N, groups, inv_count, eps);
     return dc_launch_status();
 }
 

@@ -41,7 +41,8 @@ SIGNATURES = {
     "dc_conv_small_cin_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "dc_conv_small_cout_bf16": [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "dc_gn_stats_nhwc_bf16": [vp, vp, i32, i64, i32, vp],
-    "dc_gn_finalize": [vp, i32, vp, i32, vp, vp, vp, i32, i32, i64, f32, vp],
+    "dc_gn_stats_chunks": [i64, i32],
+    "dc_gn_finalize": [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i64, f32, vp],
     "dc_gn_apply_nhwc_bf16": [vp, i32, vp, i32, vp, vp, i32, i64, i32, vp],
     "dc_fdn_modulate_nhwc_bf16": [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     "dc_layernorm_bf16": [vp, vp, vp, vp, i64, i32, f32, vp],
@@ -77,6 +78,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = c_longlong if name == "dc_conv_igemm_ws_bytes" else c_int
+    lib.dc_gn_stats_chunks.restype = c_int
     _lib = lib
     return lib
 

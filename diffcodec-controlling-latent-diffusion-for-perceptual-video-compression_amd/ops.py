@@ -177,20 +177,22 @@ def conv3x3_nchw_f32(x, pc, stride=1, silu=False):
 
 # ------------------------------------------------------------------------------------------ norms
 def gn_stats(x):
+    """-> (partials [chunks,N,C,2] fp32, chunks)"""
     _chk(x, BF16, "x")
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
-    sums = torch.empty((n, c, 2), device=x.device, dtype=F32)
-    lib.call("dc_gn_stats_nhwc_bf16", x.data_ptr(), sums.data_ptr(), n, hw, c, _stream())
-    return sums
+    chunks = lib.load().dc_gn_stats_chunks(hw, c)
+    part = torch.empty((chunks, n, c, 2), device=x.device, dtype=F32)
+    lib.call("dc_gn_stats_nhwc_bf16", x.data_ptr(), part.data_ptr(), n, hw, c, _stream())
+    return part
 
 
-def gn_finalize(sums1, gamma, beta, groups, hw, eps, sums2=None):
-    n, c1 = sums1.shape[0], sums1.shape[1]
-    c2 = 0 if sums2 is None else sums2.shape[1]
-    ab = torch.empty((n, c1 + c2, 2), device=sums1.device, dtype=F32)
-    lib.call("dc_gn_finalize", sums1.data_ptr(), c1, _ptr(sums2), c2, _ptr(gamma), _ptr(beta), ab.data_ptr(), n, groups,
-             hw, float(eps), _stream())
+def gn_finalize(part1, gamma, beta, groups, hw, eps, part2=None):
+    ch1, n, c1 = part1.shape[0], part1.shape[1], part1.shape[2]
+    ch2, c2 = (0, 0) if part2 is None else (part2.shape[0], part2.shape[2])
+    ab = torch.empty((n, c1 + c2, 2), device=part1.device, dtype=F32)
+    lib.call("dc_gn_finalize", part1.data_ptr(), c1, ch1, _ptr(part2), c2, ch2, _ptr(gamma), _ptr(beta), ab.data_ptr(), n,
+             groups, hw, float(eps), _stream())
     return ab
 
 

@@ -106,13 +106,14 @@ int dc_conv_small_cout_bf16(const void* x, const void* w, const float* bias, con
 
 /* ------------------------------------------------------------------ normalisation */
 /* GroupNorm (diffusers ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out; FDN.param_free_norm,
- * control_utils.py:24,29): per-(sample,channel) sums -> per-(sample,channel) scale/shift.
- * sums [N][C][2] fp32 must be zero on entry (dc_gn_stats zeroes it itself). */
-int dc_gn_stats_nhwc_bf16(const void* x, float* sums, int N, long long HW, int C, void* stream);
-/* Combines channel sums of cat[x1,x2] into `groups` groups; writes ab [N][C1+C2][2]. gamma/beta may be NULL
- * (affine=False, FDN). */
-int dc_gn_finalize(const float* sums1, int C1, const float* sums2, int C2, const float* gamma, const float* beta,
-                   float* ab, int N, int groups, long long HW, float eps, void* stream);
+ * control_utils.py:24,29): per-(chunk,sample,channel) partial sums -> per-(sample,channel) scale/shift.
+ * partials: fp32 [dc_gn_stats_chunks(HW,C)][N][C][2], fully written (no zeroing needed, no atomics). */
+int dc_gn_stats_chunks(long long HW, int C);
+int dc_gn_stats_nhwc_bf16(const void* x, float* partials, int N, long long HW, int C, void* stream);
+/* Sums the chunk slabs, combines the channel sums of cat[x1,x2] into `groups` groups; writes ab [N][C1+C2][2].
+ * gamma/beta may be NULL (affine=False, FDN). */
+int dc_gn_finalize(const float* sums1, int C1, int chunks1, const float* sums2, int C2, int chunks2, const float* gamma,
+                   const float* beta, float* ab, int N, int groups, long long HW, float eps, void* stream);
 /* y = (x*a+b) [SiLU]; x = cat[x1,x2] NHWC bf16. */
 int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* ab, void* y,
                           int N, long long HW, int silu, void* stream);

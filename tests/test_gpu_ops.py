@@ -152,9 +152,10 @@ def test_conv_igemm_asymmetric_operands(ops):
     assert torch.equal(from_nhwc(out), bf(ref))     # exact: integers below 2^8 scale
 
 
-def test_conv_igemm_fused_epilogues(ops):
+@pytest.mark.parametrize("n,h,w", [(2, 16, 16), (3, 8, 8), (2, 32, 32), (1, 12, 20)])
+def test_conv_igemm_fused_epilogues(ops, n, h, w):
     g = torch.Generator().manual_seed(5)
-    n, h, w, cin, cout = 2, 16, 16, 128, 160
+    cin, cout = 128, 160
     x = bf(torch.randn(n, cin, h, w, generator=g))
     wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
     b = torch.randn(cout, generator=g) * 0.1
