@@ -132,7 +132,10 @@ def main():
         return pipe(**sets[i % 2], **kw).images
 
     for i in range(args.warmup):
+        tw = time.perf_counter()
         out = one_step(i)
+        torch.cuda.synchronize()
+        log(f"[rank {rank}] warmup step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

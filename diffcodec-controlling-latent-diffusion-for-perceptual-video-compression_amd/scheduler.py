@@ -35,6 +35,8 @@ class DDIMScheduler:
     def set_timesteps(self, num_inference_steps, device=None, **kw):
         if num_inference_steps > self.num_train_timesteps:
             raise ValueError("num_inference_steps exceeds num_train_timesteps")
+        if num_inference_steps == self.num_inference_steps and self.timesteps is not None:
+            return                      # same schedule: keep the device tables (captured hipGraphs point at them)
         self.num_inference_steps = num_inference_steps
         ratio = self.num_train_timesteps // num_inference_steps
         ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
