@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1, help="inter frames decoded per step per GPU")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
     args = ap.parse_args()
 
     from diffcodec_amd import ops, sharding
@@ -156,7 +157,7 @@ def main():
 
     # ---- roofline leg (after the timed region): HIP events around every MFMA implicit-GEMM launch of one eager frame
     roof = None
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         # An eager frame is host-launch-bound (events would time the gaps), so: record every igemm launch of one eager
         # frame, then time each DISTINCT launch shape back-to-back (10 launches between two HIP events on the launch
         # stream) and weight by its count in the frame.
