@@ -1,0 +1,234 @@
+// Row-major GEMM  out[m][n] = sum_k X[m][k] * W[n][k]  for gfx950 with a multi-stage LDS-DMA pipeline — the 1x1 conv /
+// nn.Linear path (Transformer2DModel.proj_out, attention to_q/k/v/out, GEGLU feed-forward, time_emb_proj, conv_shortcut,
+// ControlNet zero-convs: call sites flownet.py:87-124, pipeline.py:358-367) whenever no transform is needed on load.
+//
+// Per workgroup: 256 threads = 4 waves as 2(m) x 2(n), tile BM x BN, BK = 64 (one 128-byte line per row per K-step).
+// Both operand tiles go global -> LDS with `global_load_lds_dwordx4` (no VGPR staging, no ds_write): one wave
+// instruction lands 8 rows x 128 B; the LDS image is lane-linear as the DMA requires, and the bank swizzle
+// (16-byte chunk index XOR (row & 7)) is applied on the per-lane SOURCE address and again on the fragment read, so
+// the v_mfma_f32_16x16x32_bf16 fragment ds_read_b128 stay conflict-free.  NST LDS stages form a ring: the DMA of
+// K-step k+NST-1 is issued right after the barrier that opens step k, and a counted `s_waitcnt vmcnt(N)` (never 0 in
+// the loop) leaves NST-2 stages in flight across every raw `s_barrier` — one barrier per K-step.
+#include "dc_common.h"
+#include "../../include/diffcodec_hip.h"
+
+namespace {
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TM, int TN, int NST>
+__global__ __launch_bounds__(256, 1) void gemm_dma_kernel(const dc_conv_desc d)
+{
+    constexpr int WM = 2, WN = 2;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    constexpr int ROWS = BM + BN;
+    constexpr int STAGE = ROWS * 128;
+    constexpr int NGW = ROWS / 32;                    // DMA wave-instructions per wave per stage (8 rows each)
+    static_assert(ROWS % 32 == 0, "rows per stage must split over 4 waves x 8-row pieces");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int HoWo = d.Ho * d.Wo;
+    const int M = d.N * HoWo;
+    const int K = d.C1 + d.C2;
+    const int KT = K >> 6;
+    const int n_tiles = (d.Cout + BN - 1) / BN;
+    const int m_tiles = (M + BM - 1) / BM;
+    const int nblk = n_tiles * m_tiles;
+    int bid = blockIdx.x;
+    {
+        const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
+    }
+    const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int kt_begin = 0, kt_end = KT;
+    if (d.splitk > 1) {
+        const int per = (KT + d.splitk - 1) / d.splitk;
+        kt_begin = blockIdx.y * per;
+        kt_end = min(KT, kt_begin + per);
+        if (kt_begin >= kt_end) return;
+    }
+    const int nk = kt_end - kt_begin;
+
+    // ---- per-lane DMA sources.  Piece g (8 rows) of a stage: rows [8g, 8g+8); lane s -> row 8g + (s>>3), LDS slot s&7,
+    //      which must hold source chunk (s&7) ^ (row&7).
+    const char* src1[NGW];                            // row base in x1 (or W) incl. the swizzled chunk offset
+    const char* src2[NGW];                            // row base in x2 (second K range) — A rows only
+    int ldsoff[NGW];
+    const int c1_steps = d.C1 >> 6;
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) {
+        const int g = wave + 4 * i;
+        const int row = g * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ (row & 7);
+        ldsoff[i] = g * 1024;
+        if (g * 8 < BM) {
+            int m = m0 + row;
+            m = m < M ? m : M - 1;                    // clamp: rows past M are computed and discarded
+            src1[i] = (const char*)d.x1 + ((long long)m * d.C1 + chunk * 8) * 2;
+            src2[i] = d.x2 ? (const char*)d.x2 + ((long long)m * d.C2 + chunk * 8) * 2 : nullptr;
+        } else {
+            int n = n0 + row - BM;
+            n = n < d.Cout ? n : d.Cout - 1;
+            src1[i] = (const char*)d.w + ((long long)n * K + chunk * 8) * 2;
+            src2[i] = nullptr;
+        }
+    }
+    auto issue_stage = [&](int kt, int slot) {
+        kt = kt < kt_end ? kt : kt_end - 1;           // past-the-end stages re-read the last one (keeps vmcnt counts constant)
+        char* base = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < NGW; ++i) {
+            const bool is_a = (wave + 4 * i) * 8 < BM;                         // wave-uniform
+            const char* p;
+            if (is_a && kt >= c1_steps) p = src2[i] + (long long)(kt - c1_steps) * 128;
+            else p = src1[i] + (long long)kt * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + ldsoff[i]), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int slot) {
+        const char* sA = smem + slot * STAGE;
+        const char* sB = sA + BM * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int swz = ((4 * s + fq) ^ (fr & 7)) << 4;
+            bf16x8 wf[TN], xf[TM];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) wf[tn] = *(const bf16x8*)(sB + ((wn * TN + tn) * 16 + fr) * 128 + swz);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) xf[tm] = *(const bf16x8*)(sA + ((wm * TM + tm) * 16 + fr) * 128 + swz);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue_stage(kt_begin + s, s);
+    for (int k = 0; k < nk; ++k) {
+        wait_vmcnt<NGW * (NST - 2)>();                // this wave's pieces of stage k have landed
+        __builtin_amdgcn_s_barrier();                 // ... and everyone else's; everyone is also done reading stage k-1
+        issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
+        compute(k % NST);
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue (same contract as igemm.hip)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 16 + fr;
+        if (m >= M) continue;
+        const int nimg = m / HoWo;
+        if (d.epilogue == 1) {
+            const int half = d.Cout >> 1;
+            bf16_t* __restrict__ o = (bf16_t*)d.out;
+#pragma unroll
+            for (int tp = 0; tp < TN / 2; ++tp) {
+                const int nb = n0 + (wn * TN + 2 * tp) * 16 + 4 * fq;
+                if (nb >= d.Cout) continue;
+                f32x4 h = acc[2 * tp][tm];
+                f32x4 g = acc[2 * tp + 1][tm];
+                if (d.bias) {
+                    h += *(const f32x4*)(d.bias + nb);
+                    g += *(const f32x4*)(d.bias + nb + 16);
+                }
+                const int col = ((n0 + (wn * TN + 2 * tp) * 16) >> 1) + 4 * fq;
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
+                *(bf16x4*)(o + (long long)m * half + col) = pk;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+            if (nb >= d.Cout) continue;
+            f32x4 v = acc[tn][tm];
+            const long long off = (long long)m * d.Cout + nb;
+            if (d.splitk > 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(d.splitk_ws + off + r, v[r]);
+                continue;
+            }
+            if (d.bias) v += *(const f32x4*)(d.bias + nb);
+            if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
+            if (d.act == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+            }
+            v *= d.out_scale;
+            if (d.residual) {
+                const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            }
+            if (d.out_f32) {
+                *(f32x4*)((float*)d.out + off) = v;
+            } else {
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                *(bf16x4*)((bf16_t*)d.out + off) = pk;
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int NST>
+int launch_gemm(const dc_conv_desc& d, hipStream_t st)
+{
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
+    const int M = d.N * d.Ho * d.Wo;
+    const int nblk = dc_cdiv(M, BM) * dc_cdiv(d.Cout, BN);
+    const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
+    const size_t lds = (size_t)NST * (BM + BN) * 128;
+    auto kern = gemm_dma_kernel<TM, TN, NST>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);
+    return dc_launch_status();
+}
+
+}  // namespace
+
+int dc_gemm_dma_supported(const dc_conv_desc& d)
+{
+    return d.ksize == 1 && d.gn_ab == nullptr;
+}
+
+int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
+{
+    const long long M = (long long)d.N * d.Ho * d.Wo;
+    const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
+    const int bn = n160 ? 160 : 128;
+    const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
+    if (big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
+    return n160 ? launch_gemm<2, 5, 4>(d, st) : launch_gemm<2, 4, 4>(d, st);
+}

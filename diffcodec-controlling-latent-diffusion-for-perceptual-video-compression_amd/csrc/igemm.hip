@@ -17,6 +17,9 @@
 // conv3x3_tile.hip: LDS-staged 2D-tile kernel for 3x3 stride-1 convs with tile-aligned outputs
 int dc_conv3x3_tile_supported(const dc_conv_desc& d);
 int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st);
+// gemm_dma.hip: LDS-DMA pipelined GEMM for 1x1 convs / linears without a load-side transform
+int dc_gemm_dma_supported(const dc_conv_desc& d);
+int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st);
 
 namespace {
 
@@ -399,7 +402,8 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     const int bn = n160 ? 160 : 128;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * d.splitk;
     int rc;
-    if (dc_conv3x3_tile_supported(d)) rc = dc_conv3x3_tile_launch(d, st);
+    if (dc_gemm_dma_supported(d)) rc = dc_gemm_dma_launch(d, st);
+    else if (dc_conv3x3_tile_supported(d)) rc = dc_conv3x3_tile_launch(d, st);
     else if (big_tiles >= 512) rc = n160 ? launch_cfg<2, 2, 4, 5>(d, st) : launch_cfg<2, 2, 4, 4>(d, st);
     else rc = n160 ? launch_cfg<2, 2, 2, 5>(d, st) : launch_cfg<2, 2, 2, 4>(d, st);
     if (rc != DC_OK) return rc;

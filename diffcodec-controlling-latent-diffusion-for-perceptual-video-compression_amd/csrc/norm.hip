@@ -56,35 +56,49 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     }
 }
 
-// One thread per (n, c): sum the group's channel sums over all chunk slabs, emit scale/shift.
-__global__ void gn_finalize_kernel(const float* __restrict__ s1, int C1, int chunks1, const float* __restrict__ s2, int C2,
-                                   int chunks2, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ ab, int N, int groups, float inv_count, float eps)
+// One wave per (sample, group): lanes stride over the group's (chunk, channel) partials, wave-reduce, then the first
+// cpg lanes emit the per-channel scale/shift.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ s1, int C1, int chunks1,
+                                                         const float* __restrict__ s2, int C2, int chunks2,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ ab, int N, int groups, float inv_count, float eps)
 {
     const int C = C1 + C2;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
     const int cpg = C / groups;
-    const int g0 = (c / cpg) * cpg;
+    const int g0 = g * cpg;
+    const int lane = threadIdx.x;
     float s = 0.f, ss = 0.f;
-    for (int k = g0; k < g0 + cpg; ++k) {
-        const bool first = k < C1;
-        const float* p = first ? s1 + ((long long)n * C1 + k) * 2 : s2 + ((long long)n * C2 + (k - C1)) * 2;
-        const long long stride = (long long)N * (first ? C1 : C2) * 2;
-        const int chunks = first ? chunks1 : chunks2;
-        for (int ch = 0; ch < chunks; ++ch) {
-            s += p[ch * stride];
-            ss += p[ch * stride + 1];
-        }
+    // channels of the group that live in the first / second source
+    const int a0 = min(g0, C1), a1 = min(g0 + cpg, C1);            // [a0,a1) in source 1
+    const int b0 = max(g0, C1) - C1, b1 = max(g0 + cpg, C1) - C1;  // [b0,b1) in source 2
+    const int w1 = a1 - a0, w2 = b1 - b0;
+    for (int i = lane; i < w1 * chunks1; i += 64) {
+        const int ch = i / w1, k = a0 + (i - ch * w1);
+        const float2 v = *(const float2*)(s1 + (((long long)ch * N + n) * C1 + k) * 2);
+        s += v.x;
+        ss += v.y;
     }
+    for (int i = lane; i < w2 * chunks2; i += 64) {
+        const int ch = i / w2, k = b0 + (i - ch * w2);
+        const float2 v = *(const float2*)(s2 + (((long long)ch * N + n) * C2 + k) * 2);
+        s += v.x;
+        ss += v.y;
+    }
+    s = dc_wave_sum(s);
+    ss = dc_wave_sum(ss);
     const float mean = s * inv_count;
     const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
     const float rstd = rsqrtf(var + eps);
-    const float ga = gamma ? gamma[c] : 1.f;
-    const float be = beta ? beta[c] : 0.f;
-    ab[(long long)i * 2] = rstd * ga;
-    ab[(long long)i * 2 + 1] = be - mean * rstd * ga;
+    for (int k = lane; k < cpg; k += 64) {
+        const int c = g0 + k;
+        const float ga = gamma ? gamma[c] : 1.f;
+        const float be = beta ? beta[c] : 0.f;
+        float2 o;
+        o.x = rstd * ga;
+        o.y = be - mean * rstd * ga;
+        *(float2*)(ab + ((long long)n * C + c) * 2) = o;
+    }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, int C1,
@@ -229,7 +243,7 @@ extern "C" int dc_gn_finalize(const float* sums1, int C1, int chunks1, const flo
     const int C = C1 + C2;
     if (!sums1 || !ab || N <= 0 || groups <= 0 || C <= 0 || C % groups || (C2 && !sums2) || chunks1 <= 0) return DC_ERR_INVALID;
     const float inv_count = 1.0f / ((float)HW * (float)(C / groups));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(dc_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(64), 0, (hipStream_t)stream,
                        sums1, C1, chunks1, sums2, C2, chunks2, gamma, beta, ab, N, groups, inv_count, eps);
     return dc_launch_status();
 }
