@@ -30,10 +30,15 @@ for (n, h, w, c1, c2, cout, k, up, gn) in SHAPES:
     f = lambda: ops.conv(x1, pc, x2=x2, gn_ab=ab, gn_silu=bool(gn), upsample=bool(up))
     for _ in range(3):
         f()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()            # replay 20 launches from a hipGraph: removes the Python launch cost
+    with torch.cuda.graph(gr):
+        for _ in range(20):
+            f()
+    gr.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20):
-        f()
+    gr.replay()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
