@@ -24,7 +24,7 @@ __device__ __forceinline__ void wait_vmcnt()
 }
 
 template <int TM, int TN, int NST>
-__global__ __launch_bounds__(256, 1) void gemm_dma_kernel(const dc_conv_desc d)
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 {
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -229,6 +229,8 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
     const int bn = n160 ? 160 : 128;
     const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
-    if (big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
-    return n160 ? launch_gemm<2, 5, 4>(d, st) : launch_gemm<2, 4, 4>(d, st);
+    // 2 LDS stages for the big tiles keep two workgroups resident per CU (2 waves per SIMD: one computes while the
+    // other waits for its DMA); the small tiles afford 3 stages at the same residency.
+    if (big >= 256) return n160 ? launch_gemm<4, 5, 2>(d, st) : launch_gemm<4, 4, 2>(d, st);
+    return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
 }
