@@ -134,38 +134,46 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
                 s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
-        // ---- online softmax (base-2 domain)
+        // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
+        //      are one FMA feeding v_exp_f32 directly; key masking only exists in the (wave-uniform) ragged last tile.
         const int kb = t * KV_TILE;
-        float mloc = -INFINITY;
+        if (kb + KV_TILE > a.Nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= a.Nk) s[j][r] = -INFINITY;
+                }
+        }
+        float mloc = s[0][0];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float x = s[j][r] * a.scale_log2e;
-                if (key >= a.Nk) x = -INFINITY;
-                s[j][r] = x;
-                mloc = fmaxf(mloc, x);
-            }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[j][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);        // 0 on the first tile (m_run = -inf, m_new finite)
-        m_run = m_new;
+        const float mc = m_new * a.scale_log2e;
         float lsum = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[j][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(s[j][r] * a.scale_log2e - mc);
                 lsum += p;
                 pf[j][r >> 3][r & 7] = (bf16_t)p;
             }
-        l_run = l_run * alpha + lsum;
+        if (__any(m_new != m_run)) {                     // the max moved for some query of this wave: rescale O and l
+            const float alpha = __builtin_amdgcn_exp2f(m_run * a.scale_log2e - mc);   // 0 on the first tile (m_run = -inf)
+            l_run *= alpha;
 #pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
+            for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
+            m_run = m_new;
+        }
+        l_run += lsum;
 
         // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
 #pragma unroll

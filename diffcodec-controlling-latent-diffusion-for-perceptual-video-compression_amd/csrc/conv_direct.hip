@@ -98,13 +98,29 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __res
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             const bf16_t* xp = x + (((long long)n * H + iy) * W + ix) * Cin;
             const bf16_t* wp = w + (long long)(ky * ks + kx) * Cin * Cout + g * 8;
-            for (int c = 0; c < Cin; ++c) {
-                const float xv = (float)xp[c];
+            if ((Cout & 7) == 0) {                       // 8 output channels = one 16-byte weight vector
+                for (int c = 0; c < Cin; ++c) {
+                    const float xv = (float)xp[c];
+                    const bf16x8 wv = *(const bf16x8*)(wp + (long long)c * Cout);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (g * 8 + j < Cout) acc[j] += xv * (float)wp[(long long)c * Cout + j];
+                    for (int j = 0; j < 8; ++j) acc[j] += xv * (float)wv[j];
+                }
+            } else {
+                for (int c = 0; c < Cin; ++c) {
+                    const float xv = (float)xp[c];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (g * 8 + j < Cout) acc[j] += xv * (float)wp[(long long)c * Cout + j];
+                }
             }
         }
+    if ((Cout & 7) == 0) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[j] + (bias ? bias[g * 8 + j] : 0.f));
+        *(bf16x8*)(out + m * Cout + g * 8) = o;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int co = g * 8 + j;
