@@ -1,0 +1,95 @@
+"""CPU: host-side logic that needs no GPU — scheduler tables vs the oracle's DDIM, checkpoint specs, timestep
+retrieval errors, GOP / shard bookkeeping."""
+import pytest
+import torch
+
+from diffcodec_amd import sharding, weights as W
+from diffcodec_amd.pipeline import retrieve_timesteps
+from diffcodec_amd.scheduler import DDIMScheduler
+
+
+def test_ddim_tables_match_oracle():
+    from oracle.pipeline_ref import DDIMRef
+    s, r = DDIMScheduler(), DDIMRef()
+    for n in (4, 20, 50):
+        s.set_timesteps(n)
+        r.set_timesteps(n)
+        assert torch.equal(s.timesteps, r.timesteps)
+        coef = s.coefficients()
+        x = torch.randn(2, 4, 8, 8)
+        e = torch.randn(2, 4, 8, 8)
+        for i, t in enumerate(s.timesteps.tolist()):
+            c = coef[i]
+            mine = c[2] * ((x - c[0] * e) / c[1]) + c[3] * e
+            torch.testing.assert_close(mine, r.step(e, t, x), rtol=1e-6, atol=1e-6)
+    s.set_timesteps(20)
+    assert s.timesteps[0].item() == 951 and s.timesteps[-1].item() == 1 and s.order == 1 and s.init_noise_sigma == 1.0
+
+
+def test_retrieve_timesteps_errors():
+    s = DDIMScheduler()
+    with pytest.raises(ValueError):
+        retrieve_timesteps(s, 10, None, timesteps=[1, 2], sigmas=[0.1])
+    with pytest.raises(ValueError):
+        retrieve_timesteps(s, None, None, timesteps=[999, 500])      # DDIM here has no custom-timestep support
+    with pytest.raises(ValueError):
+        retrieve_timesteps(s, None, None, sigmas=[1.0, 0.5])
+    ts, n = retrieve_timesteps(s, 20, None)
+    assert n == 20 and len(ts) == 20
+
+
+def test_checkpoint_specs_match_sd15_parameter_counts():
+    assert W.param_count(W.unet_spec()) == 859_520_964
+    assert W.param_count(W.vae_spec()) == 83_653_863
+    cn = W.controlnet_spec()
+    custom = {k: v for k, v in cn.items() if k.startswith("feature_extractor.") or k.startswith("fdn")}
+    assert len(custom) == 76      # 60 extractor + 16 FDN tensors (SURVEY.md §8(b) says 74; its own parameter totals, checked below, need 76)
+    assert W.param_count({k: v for k, v in cn.items() if k.startswith("feature_extractor.")}) == 16_275_204
+    assert W.param_count({k: v for k, v in cn.items() if k.startswith("fdn")}) == 40_555_520
+    assert cn["fdn16.conv_gamma.weight"][1] == (640, 640, 3, 3)
+    assert cn["feature_extractor.zero_convs.3.weight"][1] == (1280, 640, 3, 3)
+
+
+def test_filter_state_dict_is_strict_false_plus_shape_filter():
+    spec = W.controlnet_spec(dict(W.SD15_UNET_CONFIG, block_out_channels=(32, 64, 128, 128), cross_attention_dim=64))
+    sd = W.synthesize(spec, 0)
+    sd.pop("feature_extractor.wrapper.0.metric_net.0.weight")           # older checkpoints lack metric_net (pipeline.ipynb)
+    sd["fdn08.conv_beta.bias"] = torch.zeros(3)
+    sd["stray.key"] = torch.zeros(1)
+    kept, rep = W.filter_state_dict(sd, spec)
+    assert rep["missing"] == ["feature_extractor.wrapper.0.metric_net.0.weight"]
+    assert rep["mismatched"] == ["fdn08.conv_beta.bias"] and rep["unexpected"] == ["stray.key"]
+    assert "fdn08.conv_beta.bias" not in kept
+
+
+def test_gop_and_shards():
+    units = sharding.gop_inter_frames(97, 12)            # 96-frame UVG clip + closing anchor
+    assert len(units) == 88 and units[0] == (1, 0, 12) and units[-1] == (95, 84, 96)
+    assert all(f % 12 for f, _, _ in units)
+    for world in (1, 2, 3, 8):
+        got = sorted(sum((sharding.shard_units(len(units), r, world) for r in range(world)), []))
+        assert got == list(range(len(units)))             # every unit exactly once
+    assert len(sharding.shard_units(88, 0, 8)) == 11      # 88 = 8 x 11
+    with pytest.raises(ValueError):
+        sharding.shard_units(4, 4, 4)
+
+
+def test_pipeline_validation_errors_need_no_gpu():
+    from types import SimpleNamespace
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline as P
+    vae = SimpleNamespace(config=SimpleNamespace(block_out_channels=[1, 2, 3, 4], scaling_factor=0.18215))
+    unet = SimpleNamespace(config=SimpleNamespace(in_channels=4, time_cond_proj_dim=None), device=torch.device("cpu"))
+    pipe = P(vae, None, None, unet, None, DDIMScheduler(), None, None)
+    assert pipe.vae_scale_factor == 8
+    pe = torch.zeros(1, 77, 768)
+    with pytest.raises(ValueError, match="Provide both"):
+        pipe(prompt_embeds=pe)
+    with pytest.raises(ValueError, match=r"controlnet_cond must be \[B,6,H,W\]"):
+        pipe(prompt_embeds=pe, controlnet_cond=torch.zeros(1, 5, 64, 64), flow_cond=torch.zeros(1, 4, 64, 64))
+    with pytest.raises(ValueError, match=r"flow_cond must be \[B,4,H,W\]"):
+        pipe(prompt_embeds=pe, controlnet_cond=torch.zeros(1, 6, 64, 64), flow_cond=torch.zeros(1, 2, 64, 64))
+    with pytest.raises(ValueError, match="mismatch"):
+        pipe(prompt_embeds=torch.zeros(3, 77, 768), negative_prompt_embeds=torch.zeros(3, 77, 768),
+             controlnet_cond=torch.zeros(2, 6, 64, 64), flow_cond=torch.zeros(2, 4, 64, 64))
+    with pytest.raises(ValueError, match="divisible by 8"):
+        pipe(prompt_embeds=pe, negative_prompt_embeds=pe, controlnet_cond=torch.zeros(1, 6, 60, 60), flow_cond=torch.zeros(1, 4, 60, 60))
