@@ -11,6 +11,10 @@
 // The nearest-2x upsample of diffusers' Upsample2D is fused: the halo is taken from the low-resolution input and the
 // fragment positions are halved per tap.
 //
+// The weight tile of each tap goes global -> LDS by `global_load_lds_dwordx4` (LDS-DMA: no VGPR staging, no ds_write)
+// into a ring of NSTB stages; a counted `s_waitcnt vmcnt` + one raw `s_barrier` per K-step keep NSTB-2 stages in
+// flight across the barrier, so the K-loop is MFMA/LDS-paced instead of load-latency-paced.
+//
 // LDS images are row-major 128-B rows with the 16-B chunk index XORed by (row & 7): ds_write_b128 of a row piece and
 // the v_mfma_f32_16x16x32_bf16 fragment ds_read_b128 are both bank-conflict-free, and rows stay whole 128-B lines.
 #include "dc_common.h"
@@ -18,7 +22,16 @@
 
 namespace {
 
-template <int TM, int TN, bool GN>
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TM, int TN, bool GN, int NSTB>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
     constexpr int WM = 2, WN = 2;
@@ -26,16 +39,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int BN = WN * TN * 16;
     constexpr int HALO_MAX = (TH + 2) * 18;
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
-    constexpr int PB = BN / 32;
+    constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
     constexpr int H_BYTES = HALO_MAX * 128;
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sH = smem;
     char* const sB0 = smem + H_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
-    const int q = tid & 7, r0 = tid >> 3;
+    const int q = tid & 7;
     const int fr = lane & 15, fq = lane >> 4;
 
     const int Cin = d.C1 + d.C2;
@@ -89,18 +103,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         h_pix[i] = pix;
         h_lds[i] = hp * 128 + ((q ^ (hp & 7)) << 4);
     }
-    int b_row[PB];
+    // weight-tile DMA: piece g (8 rows) of a stage; lane -> row 8g + (lane>>3), LDS slot lane&7 = source chunk ^ (row&7)
+    const char* b_src[NB];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int n = n0 + r0 + 32 * i;
-        b_row[i] = n < d.Cout ? n * 9 * Cin : -1;
+    for (int i = 0; i < NB; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        int n = n0 + row;
+        n = n < d.Cout ? n : d.Cout - 1;              // rows past Cout are computed and discarded
+        b_src[i] = (const char*)d.w + ((long long)n * 9 * Cin + (((lane & 7) ^ (row & 7)) << 3)) * 2;
     }
     const bf16_t* __restrict__ x1 = (const bf16_t*)d.x1;
     const bf16_t* __restrict__ x2 = (const bf16_t*)d.x2;
     const bf16_t* __restrict__ wgt = (const bf16_t*)d.w;
     const int gn_row = GN ? (n_img % d.gn_batch) : 0;
 
-    u32x4 rh[NHU], rb[PB];
+    u32x4 rh[NHU];
     auto issue_halo = [&](int cc) {
         const int c = cc * 64 + q * 8;
         const bool second = c >= d.C1;
@@ -143,22 +160,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             *(u32x4*)(sH + h_lds[i]) = v;
         }
     };
-    auto issue_b = [&](int cc, int tap) {
-        const int off = tap * Cin + cc * 64 + q * 8;
+    const int last_step = (c_end - c_begin) * 9 - 1;
+    auto issue_b = [&](int step, int slot) {          // step = (cc - c_begin) * 9 + tap ; past-the-end re-reads the last
+        step = step < last_step ? step : last_step;
+        const int cc = c_begin + step / 9, tap = step % 9;
+        const long long off = ((long long)tap * Cin + cc * 64) * 2;
+        char* base = sB0 + slot * B_BYTES;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (b_row[i] >= 0) v = *(const u32x4*)(wgt + (long long)b_row[i] + off);
-            rb[i] = v;
-        }
-    };
-    auto store_b = [&](int buf) {
-        char* sB = sB0 + buf * B_BYTES;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int r = r0 + 32 * i;
-            *(u32x4*)(sB + r * 128 + ((q ^ (r & 7)) << 4)) = rb[i];
-        }
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + off), (lptr_t)(base + (wave + 4 * i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[TN][TM];
@@ -196,29 +206,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         }
     };
 
-    // ---- main loop: per 64-channel slice, halo once, 9 taps
+    // ---- main loop: per 64-channel slice, halo once, 9 taps; weight tiles ride the DMA ring
     issue_halo(c_begin);
-    issue_b(c_begin, 0);
+#pragma unroll
+    for (int st = 0; st < NSTB - 1; ++st) issue_b(st, st);
     store_halo(c_begin);
-    store_b(0);
-    __syncthreads();
-    int buf = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int step = 0;
     for (int cc = c_begin; cc < c_end; ++cc) {
         const bool more_c = cc + 1 < c_end;
-        for (int tap = 0; tap < 9; ++tap) {
-            const bool more = tap < 8 || more_c;
-            if (more) issue_b(tap < 8 ? cc : cc + 1, tap < 8 ? tap + 1 : 0);
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            wait_vmcnt<NB * (NSTB - 2)>();                       // this wave's pieces of weight stage `step` have landed
+            __builtin_amdgcn_s_barrier();                        // everyone's have; halo image visible; slot step-1 is free
             if (tap == 0 && more_c) issue_halo(cc + 1);          // lands under the next eight K-steps
-            compute(tap, buf);
-            if (more) store_b(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+            issue_b(step + NSTB - 1, (step + NSTB - 1) % NSTB);
+            compute(tap, step % NSTB);
         }
-        if (more_c) {                                            // every wave is past its last read of the halo image
+        if (more_c) {
+            __builtin_amdgcn_s_barrier();                        // every wave is past its last read of the halo image
             store_halo(cc + 1);
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible after the next K-step's barrier
         }
     }
+    wait_vmcnt<0>();
 
     // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3]
 #pragma unroll
@@ -260,17 +270,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int NSTB>
 int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
     const int sh = d.Wo < 16 ? 1 : 0;
     const int nblk = d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh)) * dc_cdiv(d.Cout, BN);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
-    const size_t lds = (TH + 2) * 18 * 128 + 2 * BN * 128;
+    const size_t lds = (TH + 2) * 18 * 128 + NSTB * BN * 128;
 #define DC_TILE_LAUNCH(GN)                                                                                      \
     do {                                                                                                        \
-        auto kern = conv3x3_tile_kernel<TM, TN, GN>;                                                            \
+        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB>;                                                          \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -300,6 +310,7 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     const bool n160 = d.Cout % 160 == 0;
     const int bn = n160 ? 160 : 128;
     const long long big = (long long)d.N * (d.Ho / 8) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
-    if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5>(d, st) : launch_tile<4, 4>(d, st);
-    return n160 ? launch_tile<2, 5>(d, st) : launch_tile<2, 4>(d, st);
+    // LDS budget keeps two workgroups per CU: 8-row tile with BN=160 affords a 2-stage weight ring, the others 3 stages
+    if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
+    return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }
