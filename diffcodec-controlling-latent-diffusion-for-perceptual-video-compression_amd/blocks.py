@@ -62,14 +62,14 @@ class ResnetBlock:
 
     def __call__(self, x, temb=None, x2=None):
         ab1 = ops.group_norm_ab(x, self.n1[0], self.n1[1], self.groups, self.eps, x2=x2)
-        h = ops.conv(x, self.conv1, x2=x2, gn_ab=ab1, gn_silu=True, row_add=None if temb is None else temb.slice(self.p))
+        h = ops.conv_gn_silu(x, self.conv1, ab1, x2=x2, row_add=None if temb is None else temb.slice(self.p))
         ab2 = ops.group_norm_ab(h, self.n2[0], self.n2[1], self.groups, self.eps)
         if self.shortcut is not None:
             sc = ops.conv(x, self.shortcut, x2=x2)
         else:
             assert x2 is None
             sc = x
-        return ops.conv(h, self.conv2, gn_ab=ab2, gn_silu=True, residual=sc)
+        return ops.conv_gn_silu(h, self.conv2, ab2, residual=sc)
 
 
 class TransformerBlock:

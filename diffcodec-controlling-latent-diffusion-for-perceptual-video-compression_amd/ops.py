@@ -156,6 +156,18 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     return out
 
 
+# GroupNorm+SiLU in front of a conv: folded into the conv's load stage only when the conv has a single output-channel
+# tile (Cout <= 160).  With more N-tiles every workgroup of a pixel tile would redo the same exp/rcp work (Cout/160 x
+# the 1.4x halo overlap); one HBM-bound elementwise pass (which also resolves the skip concat) is cheaper.
+FUSE_GN_MAX_COUT = 160
+
+
+def conv_gn_silu(x, pc, ab, x2=None, **kw):
+    if pc.kind == "igemm" and pc.ksize == 3 and pc.cout > FUSE_GN_MAX_COUT:
+        return conv(gn_apply(x, ab, silu=True, x2=x2), pc, **kw)
+    return conv(x, pc, x2=x2, gn_ab=ab, gn_silu=True, **kw)
+
+
 def linear(x, pc, **kw):
     """nn.Linear on rows: x [..., Cin] bf16 -> [..., Cout]."""
     shp = x.shape
