@@ -16,7 +16,12 @@
 namespace {
 
 constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key MFMA tiles)
-constexpr int VT_PITCH = KV_TILE * 2 + 8;    // bytes per V^T row: 136 -> ds_read_b64 conflict-free (17 mod 32 slots)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+// V stays row-major [key][d] in LDS (one ds_write_b128 per staged vector); the PV MFMA's A operand (V^T: 4 consecutive
+// keys of one d per lane) is fetched with the hardware transposing read ds_read_b64_tr_b16.  Row pitch = 64/192/320 B
+// (== 64 or 192 mod 256) puts the four key rows of a 4x32 block on disjoint bank ranges: conflict-free.
+__host__ __device__ constexpr int v_pitch_bytes(int ndt) { return ndt * 64 <= 64 ? 64 : (ndt * 64 <= 192 ? 192 : 320); }
 
 struct AttnArgs {
     const bf16_t* q;
@@ -37,9 +42,10 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
     constexpr int KP16 = (ND16 * 2) | 1;             // K row pitch in 16-B units, odd -> conflict-free ds_read_b128
     constexpr int K_PITCH = KP16 * 16;
     constexpr int K_BYTES = KV_TILE * K_PITCH;
-    constexpr int VT_ROWS = NDT * 32;
-    constexpr int VT_BYTES = VT_ROWS * VT_PITCH;
+    constexpr int V_PITCH = v_pitch_bytes(NDT);
+    constexpr int VT_BYTES = KV_TILE * V_PITCH;
     constexpr int BUF = K_BYTES + VT_BYTES;
+    static_assert(NDT <= 5, "head dim <= 160");
     constexpr int NLD = (KV_TILE * NV + 255) / 256;  // vectors per thread per operand per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -102,10 +108,7 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
             const int key = idx & 63, vec = idx >> 6;
             if (vec < NV) {
                 *(u32x4*)(sK + key * K_PITCH + vec * 16) = rk[i];
-                // transposed V: V^T[d][key]
-                const bf16x8 vv = *(bf16x8*)&rv[i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *(bf16_t*)(sV + (vec * 8 + j) * VT_PITCH + key * 2) = vv[j];
+                *(u32x4*)(sV + key * V_PITCH + vec * 16) = rv[i];
             }
         }
     };
@@ -176,17 +179,20 @@ __global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
         l_run += lsum;
 
         // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
+        // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
+        // and receives d = block + j16 for the block's 4 keys.
+        const char* vbase = sV + (4 * lh + ((lane & 15) >> 2)) * V_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int tt = 0; tt < NDT; ++tt) {
-            const char* vrow = sV + (32 * tt + lq) * VT_PITCH;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int k0 = 32 * j + 16 * s2 + 4 * lh;
-                    const u32x2 lo = *(const u32x2*)(vrow + k0 * 2);
-                    const u32x2 hi = *(const u32x2*)(vrow + (k0 + 8) * 2);
-                    u32x4 av = {lo[0], lo[1], hi[0], hi[1]};
+                    const char* pk = vbase + (32 * j + 16 * s2) * V_PITCH + tt * 64;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pk);
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pk + 8 * V_PITCH));
+                    u32x2 l2 = *(const u32x2*)&lo, h2 = *(const u32x2*)&hi;
+                    u32x4 av = {l2[0], l2[1], h2[0], h2[1]};
                     oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[j][s2], oacc[tt], 0, 0, 0);
                 }
         }
@@ -220,7 +226,7 @@ int launch(const AttnArgs& a, hipStream_t st)
 {
     constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
     constexpr int KP16 = (ND16 * 2) | 1;
-    constexpr int BUF = KV_TILE * KP16 * 16 + NDT * 32 * VT_PITCH;
+    constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
     const size_t lds = 2 * BUF;
     auto kern = attn_kernel<D>;
     static bool attr_set = false;
