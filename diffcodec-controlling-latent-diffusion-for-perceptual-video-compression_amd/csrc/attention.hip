@@ -33,8 +33,10 @@ struct AttnArgs {
     float scale_log2e;
 };
 
+// launch bound of 2 waves/SIMD (<= 256 registers) for the small heads: hipcc then emits the VGPR form of the MFMA;
+// at 1 wave/SIMD it parks accumulators in AGPRs and pays ~180 v_accvgpr moves per K/V tile in the softmax.
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_kernel(const AttnArgs a)
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
 {
     constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
     constexpr int NDT = (D + 31) / 32;               // 32-row output tiles of O^T
