@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=8, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
+    ap.add_argument("--frames", type=int, default=16, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
