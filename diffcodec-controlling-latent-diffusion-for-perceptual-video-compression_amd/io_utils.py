@@ -1,0 +1,71 @@
+"""Input side of the decode path — SURVEY.md §8 row a20: the reference's control loaders
+(controlnet/utils.py:10-52) with the same names, argument meaning and error behaviour.
+
+    read_flo                  utils.py:10-19   Middlebury .flo -> [H,W,2] float32 (pixel units)
+    resize_flow_to            utils.py:21-28   bilinear (align_corners=True) + vector rescale -> [1,2,h,w]
+    load_pair_to_sixch        utils.py:30-39   two RGB images (PIL, BICUBIC resize) -> [1,6,H,W] in [0,1]
+    load_controls_and_flows   utils.py:41-52   -> (controlnet_cond [1,6,H,W], flow_cond [1,4,H,W]) on `device`
+
+Host-side file I/O and preparation (the reference does the same on the CPU and then moves the tensors); the
+only dependency dropped is torchvision (`TF.to_tensor` is restated: HWC uint8 -> CHW float32 / 255)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FLO_MAGIC = 202021.25
+
+
+def read_flo(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        magic = np.fromfile(f, np.float32, 1)[0]
+        if magic != FLO_MAGIC:
+            raise ValueError(f"Invalid .flo file: {path} (magic={magic})")
+        w = int(np.fromfile(f, np.int32, 1)[0])
+        h = int(np.fromfile(f, np.int32, 1)[0])
+        data = np.fromfile(f, np.float32, 2 * w * h).reshape(h, w, 2)
+    return data
+
+
+def write_flo(path: str, flow_hw2: np.ndarray) -> None:
+    """Inverse of read_flo (used by tests and by tools that synthesise controls)."""
+    h, w, _ = flow_hw2.shape
+    with open(path, "wb") as f:
+        np.array([FLO_MAGIC], np.float32).tofile(f)
+        np.array([w, h], np.int32).tofile(f)
+        flow_hw2.astype(np.float32).tofile(f)
+
+
+def resize_flow_to(flow_hw2: np.ndarray, target_h: int, target_w: int) -> torch.Tensor:
+    ft = torch.from_numpy(np.ascontiguousarray(flow_hw2)).permute(2, 0, 1).unsqueeze(0)
+    _, _, h, w = ft.shape
+    ft = F.interpolate(ft, size=(target_h, target_w), mode="bilinear", align_corners=True)
+    ft[:, 0] *= (target_w / max(w, 1))
+    ft[:, 1] *= (target_h / max(h, 1))
+    return ft
+
+
+def _to_tensor(img) -> torch.Tensor:
+    a = np.asarray(img, dtype=np.uint8)
+    return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0)
+
+
+def load_pair_to_sixch(path0, path1, size=(512, 512)) -> torch.Tensor:
+    from PIL import Image
+
+    def load_rgb(p):
+        img = Image.open(p).convert("RGB")
+        if size is not None:
+            img = img.resize(size, Image.BICUBIC)
+        return _to_tensor(img)
+
+    return torch.cat([load_rgb(path0), load_rgb(path1)], dim=0).unsqueeze(0)
+
+
+def load_controls_and_flows(img0_path, img1_path, fwd_flo_path, bwd_flo_path, size=(512, 512), device="cuda",
+                            dtype=torch.float32):
+    h, w = size
+    sixch = load_pair_to_sixch(img0_path, img1_path, size=size).to(device=device, dtype=dtype)
+    fwd_t = resize_flow_to(read_flo(fwd_flo_path), h, w)
+    bwd_t = resize_flow_to(read_flo(bwd_flo_path), h, w)
+    flow4 = torch.cat([fwd_t, bwd_t], dim=1).to(device=device, dtype=dtype)
+    return sixch, flow4

@@ -1,0 +1,113 @@
+"""CPU: §8 rows a20 (loaders, controlnet/utils.py:10-52) and a22 (tiling, patch_utils.py).  The reference modules need
+torchvision / cv2 (absent), so they cannot be imported as a cross-check: these tests pin the file format, the documented
+arithmetic and size-independent properties (partition of unity, round trips) — parity unpinned against a reference run."""
+import numpy as np
+import pytest
+import torch
+
+from diffcodec_amd import io_utils as IO
+from diffcodec_amd import tiling as T
+
+
+def test_flo_roundtrip_and_bad_magic(tmp_path):
+    flow = np.random.RandomState(0).randn(7, 11, 2).astype(np.float32)
+    p = tmp_path / "a.flo"
+    IO.write_flo(str(p), flow)
+    raw = p.read_bytes()
+    assert len(raw) == 12 + 7 * 11 * 2 * 4 and np.frombuffer(raw[:4], np.float32)[0] == 202021.25
+    assert np.frombuffer(raw[4:12], np.int32).tolist() == [11, 7]               # width, then height
+    assert np.array_equal(IO.read_flo(str(p)), flow)
+    bad = tmp_path / "b.flo"
+    bad.write_bytes(np.array([1.0], np.float32).tobytes() + raw[4:])
+    with pytest.raises(ValueError, match="Invalid .flo"):
+        IO.read_flo(str(bad))
+
+
+def test_resize_flow_rescales_vectors_to_pixel_units():
+    flow = np.zeros((10, 20, 2), np.float32)
+    flow[..., 0] = 4.0
+    flow[..., 1] = -2.0
+    out = IO.resize_flow_to(flow, 30, 40)
+    assert out.shape == (1, 2, 30, 40)
+    assert torch.allclose(out[:, 0], torch.full((1, 30, 40), 8.0)) and torch.allclose(out[:, 1], torch.full((1, 30, 40), -6.0))
+    # align_corners=True keeps the corner samples
+    ramp = np.stack([np.tile(np.arange(20, dtype=np.float32), (10, 1)), np.zeros((10, 20), np.float32)], -1)
+    r = IO.resize_flow_to(ramp, 10, 39)
+    assert r[0, 0, 0, 0].item() == 0.0 and abs(r[0, 0, 0, -1].item() - 19.0 * 39 / 20) < 1e-5
+
+
+def test_load_controls_and_flows(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(1)
+    for n in ("f0.png", "f1.png"):
+        Image.fromarray(rs.randint(0, 255, (48, 64, 3), dtype=np.uint8)).save(tmp_path / n)
+    for n in ("fw.flo", "bw.flo"):
+        IO.write_flo(str(tmp_path / n), rs.randn(48, 64, 2).astype(np.float32))
+    six, flow = IO.load_controls_and_flows(tmp_path / "f0.png", tmp_path / "f1.png", str(tmp_path / "fw.flo"),
+                                           str(tmp_path / "bw.flo"), size=(32, 32), device="cpu")
+    assert six.shape == (1, 6, 32, 32) and flow.shape == (1, 4, 32, 32)
+    assert six.dtype == torch.float32 and 0.0 <= six.min() and six.max() <= 1.0
+    img0 = np.asarray(Image.open(tmp_path / "f0.png").convert("RGB").resize((32, 32), Image.BICUBIC), np.float32) / 255
+    assert torch.allclose(six[0, :3], torch.from_numpy(img0).permute(2, 0, 1))
+
+
+def test_crop_into_tiles_geometry_matches_the_notebook():
+    img = np.zeros((3, 1024, 1024), np.float32)
+    tiles, coords, full = T.crop_into_tiles(img, (512, 512), overlap=64, order="chw")
+    assert full == (1024, 1024) and len(tiles) == 9                               # patch_exp.ipynb: x,y in {0,448,896}
+    assert sorted({c[0] for c in coords}) == [0, 448, 896]
+    assert tiles[0].shape == (3, 512, 512) and tiles[2].shape == (3, 512, 128) and tiles[8].shape == (3, 128, 128)
+
+
+@pytest.mark.parametrize("order", ["hwc", "chw"])
+def test_merges_reconstruct_the_image(order):
+    rs = np.random.RandomState(2)
+    img = rs.randint(0, 255, (96, 130, 3)).astype(np.float32)
+    if order == "chw":
+        img = img.transpose(2, 0, 1)
+    tiles, coords, full = T.crop_into_tiles(img, (48, 64), overlap=16, order=order)
+    flat = T.merge_tiles(tiles, coords, full, order)
+    cos = T.merge_costiles(tiles, coords, full, order, feather=8)
+    assert flat.dtype == np.uint8 and flat.shape == img.shape and cos.shape == img.shape
+    assert np.abs(flat.astype(np.float32) - img).max() <= 1.0                     # weights are a partition of unity
+    # reference arithmetic kept as is: `cosine_window(f)[:f]` is a whole 0->1->0 hump, so a tile's weight vanishes at its
+    # pixels 0, f-1, h-f, h-1; where no other tile covers (the image's outer f-wide frame) the output drops to 0 there.
+    # Away from that frame every pixel has positive total weight and the normalised blend reproduces the image.
+    f = 8
+    d = np.abs(cos.astype(np.float32) - img)
+    inner = d[f:-f, f:-f] if order == "hwc" else d[:, f:-f, f:-f]
+    assert inner.max() <= 1.0
+    assert (cos[0] == 0).all() if order == "hwc" else (cos[:, 0] == 0).all()
+
+
+def test_merge_costiles_weights_follow_the_reference_formula():
+    """Two constant tiles that disagree: the output must be the weight-normalised mix with the reference's window
+    (patch_utils.py:32-48: ones, with both f-wide ends replaced by a full (cos+1)/2 hump over linspace(-pi, pi, f))."""
+    f = 16
+    hump = (np.cos(np.linspace(-np.pi, np.pi, f)) + 1) / 2
+    wx = np.ones(48)
+    wx[:f] = hump
+    wx[-f:] = hump
+    a, b = np.full((32, 48, 1), 200.0, np.float32), np.full((32, 48, 1), 100.0, np.float32)
+    out = T.merge_costiles([a, b], [(0, 32, 0, 48), (0, 32, 32, 80)], (32, 80), "hwc", feather=f)
+    wa, wb = np.zeros(80), np.zeros(80)
+    wa[0:48] = wx
+    wb[32:80] = wx
+    wy = np.ones(32)
+    wy[:f] = hump
+    wy[-f:] = hump
+    y = 20                                                                            # a row with wy > 0
+    exp = (200.0 * wa + 100.0 * wb) * wy[y] / np.maximum((wa + wb) * wy[y], 1e-8)
+    assert np.array_equal(out[y, :, 0], exp.astype(np.float32).astype(np.uint8))
+
+
+def test_latent_merge_partition_and_coordinate_quirk():
+    lat = torch.randn(1, 4, 16, 16)
+    # the function reads each tuple as (x1, x2, y1, y2) (patch_utils.py:140)
+    coords = [(0, 64, 0, 64), (64, 128, 0, 64), (0, 64, 64, 128), (64, 128, 64, 128)]
+    tiles = [lat[:, :, y1 // 8:y2 // 8, x1 // 8:x2 // 8] for (x1, x2, y1, y2) in coords]
+    merged = T.merge_latent_tiles_from_pixel_coords(tiles, coords, (1, 4, 16, 16), (128, 128))
+    w = torch.hann_window(8, periodic=False)
+    inner = (w[:, None] * w[None, :]) > 1e-6
+    m = inner.repeat(2, 2)                                                          # Hann is 0 on each tile's border
+    assert torch.allclose(merged[0, :, m], lat[0, :, m], atol=1e-5)
