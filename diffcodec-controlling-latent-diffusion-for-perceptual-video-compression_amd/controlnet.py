@@ -78,7 +78,7 @@ class HipDualFlowControlNet:
                                       block_out_channels=cfg["block_out_channels"])
         sd = state_dict
         self.enc = EncoderHalf(sd, cfg, device)
-        self.feature_extractor = BiDirFeatureExtractor(sd, "feature_extractor.", device)
+        self.feature_extractor = self._make_extractor(sd, device)
         self.fdn = []
         for name in ("fdn64", "fdn32", "fdn16", "fdn08"):
             self.fdn.append((PackedConv(sd[name + ".conv_gamma.weight"], sd[name + ".conv_gamma.bias"], device),
@@ -91,6 +91,9 @@ class HipDualFlowControlNet:
         self._ctx_key = None
         self._ctrl_key = None
         self.gamma_beta = None
+
+    def _make_extractor(self, sd, device):
+        return BiDirFeatureExtractor(sd, "feature_extractor.", device)
 
     def to(self, *a, **k):
         return self

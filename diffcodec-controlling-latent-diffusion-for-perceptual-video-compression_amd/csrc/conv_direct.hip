@@ -10,9 +10,9 @@
 namespace {
 
 constexpr int CO_T = 16;     // output channels per workgroup
-constexpr int CI_T = 8;      // input channels staged per step
 
-template <int STRIDE>
+// CI_T input channels staged per step (smaller for stride 4, whose 66x66 input patch is large)
+template <int STRIDE, int CI_T>
 __global__ __launch_bounds__(256) void conv3x3_nchw_f32_kernel(const float* __restrict__ x, long long xbs,
                                                                const float* __restrict__ w, const float* __restrict__ bias,
                                                                float* __restrict__ y, int Cin, int H, int W, int Cout,
@@ -186,12 +186,13 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __re
 extern "C" int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, const float* w, const float* bias, float* y,
                                    int N, int Cin, int H, int W, int Cout, int stride, int silu, void* stream)
 {
-    if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return DC_ERR_INVALID;
+    if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2 && stride != 4)) return DC_ERR_INVALID;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const dim3 grid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, CO_T), N);
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1) hipLaunchKernelGGL(conv3x3_nchw_f32_kernel<1>, grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
-    else hipLaunchKernelGGL(conv3x3_nchw_f32_kernel<2>, grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+    if (stride == 1) hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<1, 8>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+    else if (stride == 2) hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<2, 8>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+    else hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<4, 2>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
     return dc_launch_status();
 }
 

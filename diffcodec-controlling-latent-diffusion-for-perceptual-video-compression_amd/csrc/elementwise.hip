@@ -32,6 +32,10 @@ __global__ void silu_f32_kernel(const float* __restrict__ s, float* __restrict__
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = dc_silu(s[i]);
 }
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
 __global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long long nvec)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
@@ -171,6 +175,12 @@ extern "C" int dc_silu_f32(const float* x, float* y, long long n, void* stream)
 {
     if (!x || !y || n <= 0) return DC_ERR_INVALID;
     hipLaunchKernelGGL(silu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return dc_launch_status();
+}
+extern "C" int dc_add_f32(const float* a, const float* b, float* y, long long n, void* stream)
+{
+    if (!a || !b || !y || n <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
     return dc_launch_status();
 }
 extern "C" int dc_add_bf16(const void* a, const void* b, void* y, long long n, void* stream)

@@ -89,11 +89,10 @@ __global__ __launch_bounds__(256) void occlusion_kernel(const float* __restrict_
 
 // F.interpolate(bilinear, align_corners=False) + per-component division  (control_utils.py:87-96)
 __global__ __launch_bounds__(256) void flow_resize_kernel(const float* __restrict__ src, long long sbs, float* __restrict__ dst,
-                                                          int N, int H, int W, int h, int w)
+                                                          int N, int H, int W, int h, int w, float norm_w, float norm_h)
 {
     const long long total = (long long)N * 2 * h * w;
     const float sy = (float)H / (float)h, sx = (float)W / (float)w;
-    const float norm_w = (float)(w - 1) / 2.0f, norm_h = (float)(h - 1) / 2.0f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ox = (int)(i % w), oy = (int)((i / w) % h);
         const int c = (int)((i / ((long long)w * h)) % 2);
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(const float* __restrict__ wf,
         const float a = fmaxf(cf[n * hw + p], 0.f), b = fmaxf(cb[n * hw + p], 0.f);
         const float wsum = (a + b) + 1e-6f;
         float v = (a / wsum) * wf[i] + (b / wsum) * wl[i];
-        if (of[n * hw + p] + ob[n * hw + p] > 1.5f) v = 0.5f * (wf[i] + wl[i]);
+        if (of && of[n * hw + p] + ob[n * hw + p] > 1.5f) v = 0.5f * (wf[i] + wl[i]);
         fused[i] = v;
     }
 }
@@ -179,7 +178,16 @@ extern "C" int dc_flow_resize_normalize_f32(const float* src, long long src_batc
 {
     if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || h <= 1 || w <= 1) return DC_ERR_INVALID;
     hipLaunchKernelGGL(flow_resize_kernel, dim3(grid_for((long long)N * 2 * h * w)), dim3(256), 0, (hipStream_t)stream, src,
-                       src_batch_stride, dst, N, H, W, h, w);
+                       src_batch_stride, dst, N, H, W, h, w, (float)(w - 1) / 2.0f, (float)(h - 1) / 2.0f);
+    return dc_launch_status();
+}
+
+extern "C" int dc_flow_resize_divide_f32(const float* src, long long src_batch_stride, float* dst, int N, int H, int W,
+                                         int h, int w, float div_x, float div_y, void* stream)
+{
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || div_x == 0.f || div_y == 0.f) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(flow_resize_kernel, dim3(grid_for((long long)N * 2 * h * w)), dim3(256), 0, (hipStream_t)stream, src,
+                       src_batch_stride, dst, N, H, W, h, w, div_x, div_y);
     return dc_launch_status();
 }
 
@@ -187,7 +195,7 @@ extern "C" int dc_fuse_warped_f32(const float* warped_first, const float* warped
                                   const float* conf_b, const float* occ_f, const float* occ_b, float* fused, int N,
                                   int C, int H, int W, void* stream)
 {
-    if (!warped_first || !warped_last || !conf_f || !conf_b || !occ_f || !occ_b || !fused) return DC_ERR_INVALID;
+    if (!warped_first || !warped_last || !conf_f || !conf_b || !fused || (!occ_f != !occ_b)) return DC_ERR_INVALID;
     hipLaunchKernelGGL(fuse_kernel, dim3(grid_for((long long)N * C * H * W)), dim3(256), 0, (hipStream_t)stream,
                        warped_first, warped_last, conf_f, conf_b, occ_f, occ_b, fused, N, C, (long long)H * W);
     return dc_launch_status();

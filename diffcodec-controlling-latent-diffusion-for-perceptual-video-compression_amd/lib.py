@@ -30,6 +30,7 @@ SIGNATURES = {
     "dc_splat_sum_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
     "dc_occlusion_mask_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "dc_flow_resize_normalize_f32": [vp, i64, vp, i32, i32, i32, i32, i32, vp],
+    "dc_flow_resize_divide_f32": [vp, i64, vp, i32, i32, i32, i32, i32, f32, f32, vp],
     "dc_fuse_warped_f32": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "dc_conv3x3_nchw_f32": [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "dc_nchw_f32_to_nhwc_bf16": [vp, vp, i32, i32, i32, i32, vp],
@@ -53,6 +54,7 @@ SIGNATURES = {
     "dc_vae_sample_latents": [vp, vp, vp, f32, i32, i32, i32, i32, vp],
     "dc_silu_f32": [vp, vp, i64, vp],
     "dc_add_bf16": [vp, vp, vp, i64, vp],
+    "dc_add_f32": [vp, vp, vp, i64, vp],
     "dc_cfg_ddim_step": [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_latents_to_model_input": [vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_postprocess_image": [vp, vp, vp, i32, i32, i32, i32, vp],

@@ -183,6 +183,7 @@ def conv3x3_nchw_f32(x, pc, stride=1, silu=False):
     assert x.dtype == F32 and x.is_cuda
     n, c, h, w = x.shape
     assert x.stride(3) == 1 and x.stride(2) == w and x.stride(1) == h * w, "need dense CHW planes"
+    assert stride in (1, 2, 4)
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     y = torch.empty((n, pc.cout, ho, wo), device=x.device, dtype=F32)
     lib.call("dc_conv3x3_nchw_f32", x.data_ptr(), x.stride(0), pc.w.data_ptr(), _ptr(pc.bias), y.data_ptr(), n, c, h, w,
@@ -384,12 +385,30 @@ def flow_resize_normalize(flow2, th, tw):
     return out
 
 
-def fuse_warped(wf, wl, cf, cb, of, ob):
+def fuse_warped(wf, wl, cf, cb, of=None, ob=None):
     n, c, h, w = wf.shape
     out = torch.empty_like(wf)
-    lib.call("dc_fuse_warped_f32", wf.data_ptr(), wl.data_ptr(), cf.data_ptr(), cb.data_ptr(), of.data_ptr(), ob.data_ptr(),
+    lib.call("dc_fuse_warped_f32", wf.data_ptr(), wl.data_ptr(), cf.data_ptr(), cb.data_ptr(), _ptr(of), _ptr(ob),
              out.data_ptr(), n, c, h, w, _stream())
     return out
+
+
+def flow_resize_divide(flow2, th, tw, div_x, div_y):
+    assert flow2.dtype == F32 and flow2.is_cuda and flow2.shape[1] == 2
+    n, _, h, w = flow2.shape
+    assert flow2.stride(3) == 1 and flow2.stride(2) == w and flow2.stride(1) == h * w
+    out = torch.empty((n, 2, th, tw), device=flow2.device, dtype=F32)
+    lib.call("dc_flow_resize_divide_f32", flow2.data_ptr(), flow2.stride(0), out.data_ptr(), n, h, w, th, tw, float(div_x),
+             float(div_y), _stream())
+    return out
+
+
+def add_f32(a, b):
+    _chk(a, F32, "a")
+    _chk(b, F32, "b")
+    y = torch.empty_like(a)
+    lib.call("dc_add_f32", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream())
+    return y
 
 
 # ------------------------------------------------------------------------------------------ scheduler step / io

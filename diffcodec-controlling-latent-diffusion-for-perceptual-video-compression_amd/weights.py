@@ -163,6 +163,57 @@ def controlnet_spec(cfg=SD15_UNET_CONFIG):
     return spec
 
 
+def rescontrolnet_spec(cfg=SD15_UNET_CONFIG):
+    """ResControlNet state dict (flow_resnet.py:23-48): same encoder / FDN / zero-convs, `feature_extractor.*` is the
+    Bi_Dir_ResidueExtractor (extractors.py:78-147), plus `warp_extractor.*` (extractors.py:31-48)."""
+    spec = OrderedDict()
+    skip = _encoder_half(spec, cfg)
+    for i, c in enumerate(skip):
+        spec[f"controlnet_down_blocks.{i}.weight"] = ("zero_w", (c, c, 1, 1))
+        spec[f"controlnet_down_blocks.{i}.bias"] = ("zero_b", (c,))
+    cm = cfg["block_out_channels"][-1]
+    spec["controlnet_mid_block.weight"] = ("zero_w", (cm, cm, 1, 1))
+    spec["controlnet_mid_block.bias"] = ("zero_b", (cm,))
+    inj = inject_channels(cfg)
+    half = [c // 2 for c in inj]
+    p = "feature_extractor."
+    for side in ("prev", "next"):
+        for idx, (ci, co) in zip((0, 2, 4), ((3, 32), (32, 64), (64, 64))):
+            spec[f"{p}{side}_pre.{idx}.weight"] = ("w", (co, ci, 3, 3))
+            spec[f"{p}{side}_pre.{idx}.bias"] = ("b", (co,))
+        cin = 64
+        for i in range(4):
+            spec[f"{p}{side}_pyramids.{i}.0.weight"] = ("w", (half[i], cin, 3, 3))
+            spec[f"{p}{side}_pyramids.{i}.0.bias"] = ("b", (half[i],))
+            cin = half[i]
+    for i, fe in enumerate((16, 16, 32, 32)):
+        spec[f"{p}flow_refiners.{i}.weight"] = ("w", (2, 1, 3, 3))
+        spec[f"{p}flow_refiners.{i}.bias"] = ("b", (2,))
+        spec[f"{p}flow_feature_encoders.{i}.weight"] = ("w", (fe, 2, 3, 3))        # defined, never used in forward
+        spec[f"{p}flow_feature_encoders.{i}.bias"] = ("b", (fe,))
+        spec[f"{p}warpers.{i}.metric_net.0.weight"] = ("w", (64, half[i], 3, 3))
+        spec[f"{p}warpers.{i}.metric_net.0.bias"] = ("b", (64,))
+        spec[f"{p}warpers.{i}.metric_net.2.weight"] = ("w", (1, 64, 3, 3))
+        spec[f"{p}warpers.{i}.metric_net.2.bias"] = ("b", (1,))
+        spec[f"{p}zero_convs.{i}.weight"] = ("zero_w", (inj[i], half[i], 3, 3))
+        spec[f"{p}zero_convs.{i}.bias"] = ("zero_b", (inj[i],))
+    q = "warp_extractor."
+    chans = [(3, 64), (64, inj[0]), (inj[0], inj[1]), (inj[1], inj[2]), (inj[2], inj[3])]
+    for i, (ci, co) in enumerate(chans, start=1):
+        spec[f"{q}enc{i}.block.0.weight"] = ("w", (co, ci, 3, 3))
+        spec[f"{q}enc{i}.block.0.bias"] = ("b", (co,))
+        spec[f"{q}enc{i}.block.2.weight"] = ("w", (co, co, 3, 3))
+        spec[f"{q}enc{i}.block.2.bias"] = ("b", (co,))
+    for i in range(4):
+        spec[f"{q}zero_convs.{i}.weight"] = ("zero_w", (inj[i], inj[i], 3, 3))
+        spec[f"{q}zero_convs.{i}.bias"] = ("zero_b", (inj[i],))
+    for name, c in zip(("fdn64", "fdn32", "fdn16", "fdn08"), inj):
+        for g in ("conv_gamma", "conv_beta"):
+            spec[f"{name}.{g}.weight"] = ("w", (c, c, 3, 3))
+            spec[f"{name}.{g}.bias"] = ("b", (c,))
+    return spec
+
+
 def vae_spec(cfg=SD15_VAE_CONFIG):
     spec = OrderedDict()
     boc = cfg["block_out_channels"]

@@ -41,13 +41,18 @@ int dc_occlusion_mask_f32(const float* flow_a, const float* flow_b, float* mask_
  * caller pass flow[:, :2] / flow[:, 2:] views of the [N,4,H,W] control, extractors.py:268-269). */
 int dc_flow_resize_normalize_f32(const float* src, long long src_batch_stride, float* dst,
                                  int N, int H, int W, int h, int w, void* stream);
-/* Confidence fusion + double-hole fill — controlnet/extractors.py:297-310. All [N,*,H,W] fp32. */
+/* Bi_Dir_ResidueExtractor's flow scaling — controlnet/extractors.py:181-183: bilinear (align_corners=False) then u/div_x,
+ * v/div_y (div = 512/res: pixel rescale instead of the grid-style normalisation above). */
+int dc_flow_resize_divide_f32(const float* src, long long src_batch_stride, float* dst, int N, int H, int W, int h, int w,
+                              float div_x, float div_y, void* stream);
+/* Confidence fusion + double-hole fill — controlnet/extractors.py:297-310. All [N,*,H,W] fp32.
+ * occ_f = occ_b = NULL: fusion only (Bi_Dir_ResidueExtractor, extractors.py:199-203, has no hole fill). */
 int dc_fuse_warped_f32(const float* warped_first, const float* warped_last, const float* conf_f,
                        const float* conf_b, const float* occ_f, const float* occ_b, float* fused,
                        int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------ fp32 NCHW direct conv (extractor) */
-/* nn.Conv2d(k=3, padding=1, stride s) [+ SiLU] of the control extractors — controlnet/extractors.py:215-262,
+/* nn.Conv2d(k=3, padding=1, stride s in {1,2,4}) [+ SiLU] of the control extractors — controlnet/extractors.py:215-262,
  * control_utils.py:43-47.  x [N,Cin,H,W] (batch stride given, for channel-sliced views), w OIHW fp32. */
 int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, const float* w, const float* bias, float* y,
                         int N, int Cin, int H, int W, int Cout, int stride, int silu, void* stream);
@@ -145,6 +150,7 @@ int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void*
 int dc_vae_sample_latents(const float* moments, const float* noise, float* latents, float scale, int N, int C, int H, int W, void* stream);
 int dc_silu_f32(const float* x, float* y, long long n, void* stream);
 int dc_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+int dc_add_f32(const float* a, const float* b, float* y, long long n, void* stream);   /* P + W pyramids, flow_resnet.py:90 */
 /* CFG combine + DDIM step — pipeline.py:370-375.  eps fp32 NHWC [cfg?2B:B][h][w][4]; latents fp32 NCHW in/out;
  * coef_dev [steps][4] = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)}; step_dev int32 counter (incremented).
  * Also writes the next model input NHWC bf16 [cfg?2B:B][h][w][C]. */

@@ -151,3 +151,54 @@ def test_smoke_entry():
         pytest.skip("needs a GPU")
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_rescontrolnet_config4_operator():
+    """§8 a21: ResControlNet (flow_resnet.py) — residue + warp pyramids, then the shared encoder path."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import selftest as T, weights as W
+    from diffcodec_amd.rescontrolnet import HipResControlNet
+    from diffcodec_amd.synthetic import synth_controls, synth_text
+    from oracle import control_ref as C, sd15_ref as M
+    cfg = T.SMALL_UNET
+    sd = W.synthesize(W.rescontrolnet_spec(cfg), 5)
+    net = HipResControlNet(sd, cfg, DEV)
+    cond, flow = synth_controls(2, 256)
+    warp = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(9))
+    pe, _ = synth_text(2, dim=cfg["cross_attention_dim"])
+    x = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(10))
+    # pyramids (fp32 stage)
+    ref_p = C.bi_dir_residue_extractor(sd, "feature_extractor.", cond[:, :3], cond[:, 3:], flow[:, :2], flow[:, 2:])
+    ref_w = C.warp_extractor(sd, "warp_extractor.", warp)
+    pyr = net.compute_pyramid(cond, flow, warp)
+    for o, a, b in zip(pyr, ref_p, ref_w):
+        r = a + b
+        bad = ((o.cpu() - r).abs() > 1e-3 + 1e-3 * r.abs()).float().mean().item()
+        assert bad < 5e-3, bad
+    rd, rm = M.dualflow_controlnet_forward(sd, cfg, x, 401, pe, cond, flow, 1.3, warp_cond=warp, residual_variant=True)
+    down, mid = net(sample=x.to(DEV), timestep=401, encoder_hidden_states=pe.to(DEV), controlnet_cond=cond.to(DEV),
+                    flow_cond=flow.to(DEV), warp_cond=warp.to(DEV), conditioning_scale=1.3, return_dict=False)
+    for d, r in zip(down + [mid], rd + [rm]):
+        assert T.rel_l2(d.float().cpu(), r) < 4e-2
+    with pytest.raises(ValueError):
+        net(sample=x.to(DEV), timestep=401, encoder_hidden_states=pe.to(DEV), controlnet_cond=cond.to(DEV), flow_cond=flow.to(DEV))
+
+
+def test_residue_extractor_golden_512(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import numpy as np
+    from diffcodec_amd.rescontrolnet import BiDirResidueExtractor
+    from diffcodec_amd.synthetic import synth_controls
+    z = np.load(os.path.join(golden_dir, "control_residue512.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    fe = BiDirResidueExtractor(sd, "", DEV)
+    cond, flow = synth_controls(1, 512, seed=1234)
+    cond, flow = cond.to(DEV), flow.to(DEV)
+    outs = fe(cond[:, :3], cond[:, 3:], flow[:, :2], flow[:, 2:])
+    for i, o in enumerate(outs):
+        r = torch.from_numpy(z[f"p{i}"])
+        bad = ((o.cpu() - r).abs() > 1e-3 + 1e-3 * r.abs()).float().mean().item()
+        assert bad < 5e-3, (i, bad)
