@@ -202,3 +202,38 @@ def test_residue_extractor_golden_512(golden_dir):
         r = torch.from_numpy(z[f"p{i}"])
         bad = ((o.cpu() - r).abs() > 1e-3 + 1e-3 * r.abs()).float().mean().item()
         assert bad < 5e-3, (i, bad)
+
+
+def test_full_size_sd15_controlnet_unet_step():
+    """True SD-1.5 widths (320/640/1280, d=40/80/160 heads, 77x768 text) at 512x512: one CFG model step
+    (DualFlowControlNet + UNet, model batch 2) against the fp32 oracle.  ~1.3 TFLOP on the CPU: tens of seconds."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import selftest as T, weights as W
+    from diffcodec_amd.controlnet import HipDualFlowControlNet
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    from diffcodec_amd.unet import HipUNet2DConditionModel
+    from oracle import sd15_ref as M
+    cfg = W.SD15_UNET_CONFIG
+    usd, csd = W.synthesize(W.unet_spec(), 0), W.synthesize(W.controlnet_spec(), 1)
+    cond, flow = synth_controls(1, 512)
+    pe, npe = synth_text(1)
+    lat = synth_latents(1, 512)
+    ctx, x = torch.cat([npe, pe], 0), torch.cat([lat, lat], 0)
+    cc, fc = torch.cat([cond, cond], 0), torch.cat([flow, flow], 0)
+    with torch.no_grad():
+        rd, rm = M.dualflow_controlnet_forward(csd, cfg, x, 951, ctx, cc, fc, 1.7)
+        re = M.unet_forward(usd, cfg, x, 951, ctx, rd, rm)
+    cn = HipDualFlowControlNet(csd, cfg, DEV)
+    un = HipUNet2DConditionModel(usd, cfg, DEV)
+    del usd, csd
+    down, mid = cn(sample=x.to(DEV), timestep=951, encoder_hidden_states=ctx.to(DEV), controlnet_cond=cc.to(DEV),
+                   flow_cond=fc.to(DEV), conditioning_scale=1.7, return_dict=False)
+    shapes = [tuple(d.shape[1:]) for d in down]
+    assert shapes == [(320, 64, 64)] * 3 + [(320, 32, 32)] + [(640, 32, 32)] * 2 + [(640, 16, 16)] + [(1280, 16, 16)] * 2 + [(1280, 8, 8)] * 3
+    for d, r in zip(down + [mid], rd + [rm]):
+        assert T.rel_l2(d.float().cpu(), r) < 4e-2
+    eps = un(x.to(DEV), 951, encoder_hidden_states=ctx.to(DEV), down_block_additional_residuals=down,
+             mid_block_additional_residual=mid, return_dict=False)[0]
+    assert tuple(eps.shape) == (2, 4, 64, 64)
+    assert T.rel_l2(eps.float().cpu(), re) < 5e-2
