@@ -192,9 +192,18 @@ def main():
             for r in rows:
                 fh.write(f"{r[0]:9.3f} {r[1]:5d} {r[2]:9.2f} {r[3]:8.1f} {r[4]}\n")
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        traffic, traffic_note = None, "no PMC summary committed"
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
+        if os.path.exists(pmc):       # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
+            with open(pmc) as fh:
+                sh = json.load(fh)["shapes"][0]
+            traffic = sh["hbm_bytes"]
+            traffic_note = (f"HBM bytes per launch of {sh['shape']}: 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
+                            f"(profiles/r01_pmc_igemm.json), {sh['ratio']}x its algorithmic {sh['algorithmic_bytes']} B")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                    traffic=None, kernel="igemm_kernel (dc_conv_igemm_bf16)", launches_per_frame=len(recs),
-                    avg_launch_us=round(tot_ms * 1e3 / max(1, len(recs)), 2), igemm_ms_per_frame=round(tot_ms, 2),
+                    traffic=traffic, traffic_note=traffic_note,
+                    kernel="dc_conv_igemm_bf16 family: conv3x3_tile_kernel / gemm_dma_kernel / igemm_kernel", launches_per_step=len(recs),
+                    avg_launch_us=round(tot_ms * 1e3 / max(1, len(recs)), 2), igemm_ms_per_step=round(tot_ms, 2),
                     note="sum of algorithmic 2*M*N*K over the igemm launches of one frame / sum of their HIP-event launch durations "
                          "(each distinct launch shape timed back-to-back x10 on the launch stream, weighted by its count)")
     cpu = None
