@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     constexpr int VT_BYTES = KV_TILE * V_PITCH;
     constexpr int BUF = K_BYTES + VT_BYTES;
     static_assert(NDT <= 5, "head dim <= 160");
+    // Row sums for free: when the head dim leaves a spare zero-padded column (d = 40, 80, 8, 16), V's column D is set to
+    // 1.0 in LDS, so O^T row D accumulates sum_k p — the softmax denominator — inside the PV MFMA, already rescaled by
+    // the running-max correction.  Saves one v_add_f32 per probability.
+    constexpr bool ONES = (D % 32) != 0;
+    constexpr int ONES_T = D / 32, ONES_R = ((D % 32) & 3) + 4 * ((D % 32) >> 3);
+    static_assert(!ONES || ((D % 32) % 8) < 4, "ones row must live in the lower lane half");
     constexpr int NLD = (KV_TILE * NV + 255) / 256;  // vectors per thread per operand per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -65,6 +71,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     // zero both LDS buffers once: pad columns (d >= D) and never-written bytes must be finite zeros
     for (int i = tid * 16; i < 2 * BUF; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    if (ONES) {
+        __syncthreads();
+        if (tid < 2 * KV_TILE)
+            *(unsigned short*)(smem + (tid >> 6) * BUF + K_BYTES + (tid & 63) * V_PITCH + D * 2) = 0x3F80;   // bf16 1.0
+    }
 
     // Q^T fragments: lane holds Q[q0+lq][16*ks + 8*lh .. +7]
     bf16x8 qf[ND16];
@@ -161,24 +172,29 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         const float mc = m_new * a.scale_log2e;
         float lsum = 0.f;
         bf16x8 pf[2][2];
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 c2 = {a.scale_log2e, a.scale_log2e}, mc2 = {mc, mc};
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[j][r] * a.scale_log2e - mc);
-                lsum += p;
-                pf[j][r >> 3][r & 7] = (bf16_t)p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {s[j][r], s[j][r + 1]};
+                const f32x2 t = sv * c2 - mc2;                   // v_pk_fma_f32
+                const float p0 = __builtin_amdgcn_exp2f(t[0]), p1 = __builtin_amdgcn_exp2f(t[1]);
+                if (!ONES) lsum += p0 + p1;
+                pf[j][r >> 3][r & 7] = (bf16_t)p0;
+                pf[j][r >> 3][(r & 7) + 1] = (bf16_t)p1;
             }
         if (__any(m_new != m_run)) {                     // the max moved for some query of this wave: rescale O and l
             const float alpha = __builtin_amdgcn_exp2f(m_run * a.scale_log2e - mc);   // 0 on the first tile (m_run = -inf)
-            l_run *= alpha;
+            if (!ONES) l_run *= alpha;
 #pragma unroll
             for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
             m_run = m_new;
         }
-        l_run += lsum;
+        if (!ONES) l_run += lsum;
 
         // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
         // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
@@ -203,7 +219,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
 
     // ---- finish: O[q][d] = O^T[d][q] / l
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (ONES) l_tot = __shfl(oacc[ONES_T][ONES_R], lq, 64);          // row D of O^T lives in the lower lane half
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + lq;
     if (qi < a.Nq) {
