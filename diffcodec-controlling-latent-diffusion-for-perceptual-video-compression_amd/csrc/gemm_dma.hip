@@ -136,7 +136,81 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     }
     wait_vmcnt<0>();
 
-    // ---- epilogue (same contract as igemm.hip)
+    // ---- epilogue.  bf16 outputs go through LDS so that global stores (and residual loads) are whole 16-byte pieces of
+    //      contiguous output rows: the MFMA layout gives each lane 4 channels of one pixel, i.e. 32-byte row fragments
+    //      per store instruction; staged, every row leaves as BN*2 contiguous bytes.
+    const bool staged = !d.out_f32 && d.splitk <= 1;
+    if (staged) {
+        constexpr int OC = BN;                                  // staged columns (GEGLU halves it below)
+        constexpr int PITCH = OC * 2 + 16;                      // bytes per staged row (+16: spread rows over banks)
+        static_assert(BM * PITCH <= NST * STAGE, "output tile must fit in the stage buffers");
+        __syncthreads();                                        // all waves are done reading the last stage
+        const int ocols = d.epilogue == 1 ? OC / 2 : OC;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = (wm * TM + tm) * 16 + fr;
+            const int m = m0 + row;
+            const int nimg = (m < M ? m : M - 1) / HoWo;
+            if (d.epilogue == 1) {
+#pragma unroll
+                for (int tp = 0; tp < TN / 2; ++tp) {
+                    const int nb = n0 + (wn * TN + 2 * tp) * 16 + 4 * fq;
+                    f32x4 h = acc[2 * tp][tm];
+                    f32x4 g = acc[2 * tp + 1][tm];
+                    if (d.bias && nb < d.Cout) {
+                        h += *(const f32x4*)(d.bias + nb);
+                        g += *(const f32x4*)(d.bias + nb + 16);
+                    }
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
+                    *(bf16x4*)(smem + row * PITCH + (((wn * TN + 2 * tp) * 16) / 2 + 4 * fq) * 2) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int nl = (wn * TN + tn) * 16 + 4 * fq;
+                    const int nb = n0 + nl;
+                    f32x4 v = acc[tn][tm];
+                    if (nb < d.Cout) {
+                        if (d.bias) v += *(const f32x4*)(d.bias + nb);
+                        if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
+                    }
+                    if (d.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+                    }
+                    v *= d.out_scale;
+                    if (d.residual) {                           // keep fp32 until the residual is added: stage as fp32? no —
+                        // the residual is added in the store pass below on the bf16-rounded product, which would round twice;
+                        // instead fetch it here (8-byte loads) only when present
+                        if (m < M && nb < d.Cout) {
+                            const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + (long long)m * d.Cout + nb);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                        }
+                    }
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
+                    *(bf16x4*)(smem + row * PITCH + nl * 2) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        // cooperative store: consecutive lanes -> consecutive 16-byte pieces of one output row
+        const int out_cols = d.epilogue == 1 ? d.Cout >> 1 : d.Cout;
+        const int col0 = d.epilogue == 1 ? n0 >> 1 : n0;
+        const int pieces = ocols / 8;                           // 16-byte pieces per staged row
+        bf16_t* __restrict__ o = (bf16_t*)d.out;
+        for (int i = tid; i < BM * pieces; i += 256) {
+            const int row = i / pieces, pc = i - row * pieces;
+            const int m = m0 + row, c = col0 + pc * 8;
+            if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
+        }
+        return;
+    }
+    // ---- direct epilogue (fp32 outputs, split-K partials): same contract as igemm.hip
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int m = m0 + (wm * TM + tm) * 16 + fr;
