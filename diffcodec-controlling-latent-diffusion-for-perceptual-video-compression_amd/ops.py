@@ -86,7 +86,7 @@ def _pick_splitk(m, cout, kt):
     m*cout*4*splitk bytes must stay small next to the weight stream)."""
     bn = 160 if cout % 160 == 0 else 128
     tiles = math.ceil(m / 64) * math.ceil(cout / bn)
-    if tiles >= 384 or kt < 16:
+    if tiles >= 384 or kt < 64:
         return 1
     return int(max(1, min(16, kt // 8, math.ceil(512 / tiles))))
 
