@@ -106,6 +106,8 @@ def main():
     rank, local, world = sharding.init_from_env()
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("DC_FORCE_DEVICE") is not None:      # rehearsal of the N>1 path on a 1-GPU box (with DC_DIST_BACKEND=gloo)
+        local = int(os.environ["DC_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
