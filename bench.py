@@ -164,14 +164,11 @@ def main():
         # frame, then time each DISTINCT launch shape back-to-back (10 launches between two HIP events on the launch
         # stream) and weight by its count in the frame.
         pipe.enable_hip_graphs(False)
-        ops.PROFILE = []
+        ops.PROFILE = {}
         one_step(0)
         torch.cuda.synchronize()
-        recs, ops.PROFILE = ops.PROFILE, None
-        uniq = {}
-        for flops, label, relaunch in recs:
-            u = uniq.setdefault(label, [0, flops, relaunch])
-            u[0] += 1
+        uniq, ops.PROFILE = ops.PROFILE, None
+        n_launches = sum(u[0] for u in uniq.values())
         tot_ms = tot_fl = 0.0
         rows = []
         for label, (cnt, flops, relaunch) in uniq.items():
@@ -204,8 +201,8 @@ def main():
                             f"(profiles/r01_pmc_igemm.json), {sh['ratio']}x its algorithmic {sh['algorithmic_bytes']} B")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
                     traffic=traffic, traffic_note=traffic_note,
-                    kernel="dc_conv_igemm_bf16 family: conv3x3_tile_kernel / gemm_dma_kernel / igemm_kernel", launches_per_step=len(recs),
-                    avg_launch_us=round(tot_ms * 1e3 / max(1, len(recs)), 2), igemm_ms_per_step=round(tot_ms, 2),
+                    kernel="dc_conv_igemm_bf16 family: conv3x3_tile_kernel / gemm_dma_kernel / igemm_kernel", launches_per_step=n_launches,
+                    avg_launch_us=round(tot_ms * 1e3 / max(1, n_launches), 2), igemm_ms_per_step=round(tot_ms, 2),
                     note="sum of algorithmic 2*M*N*K over the igemm launches of one frame / sum of their HIP-event launch durations "
                          "(each distinct launch shape timed back-to-back x10 on the launch stream, weighted by its count)")
     cpu = None
