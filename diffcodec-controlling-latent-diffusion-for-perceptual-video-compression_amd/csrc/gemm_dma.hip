@@ -306,7 +306,11 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
     // 2 LDS stages for the big tiles keep two workgroups resident per CU (2 waves per SIMD: one computes while the
     // other waits for its DMA); the small tiles afford 3 stages at the same residency.
-    static const int force_nst = getenv("DC_GEMM_NST") ? atoi(getenv("DC_GEMM_NST")) : 0;   // developer knob
+    static const int force_nst = getenv("DC_GEMM_NST") ? atoi(getenv("DC_GEMM_NST")) : 0;   // developer knobs
+    static const int force_small = getenv("DC_GEMM_SMALL") ? atoi(getenv("DC_GEMM_SMALL")) : 0;
+    if (force_small == 1) return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
+    if (force_small == 2) return launch_gemm<2, 2, 3>(d, st);
+    if (force_small == 3) return launch_gemm<2, 4, 2>(d, st);
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
     if (force_nst == 3 && big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
     if (big >= 256) return n160 ? launch_gemm<4, 5, 2>(d, st) : launch_gemm<4, 4, 2>(d, st);
