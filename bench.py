@@ -157,6 +157,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
+    # ---- single-frame latency configuration (BASELINE configs[1] read literally: one 512x512 frame per pass), reported
+    #      beside `value`; measured after the timed region, never part of it
+    single = None
+    if rank == 0 and F != 1 and not args.no_roofline:
+        one = [{k: v[:1].contiguous() for k, v in s_.items()} for s_ in sets]
+        for i in range(2):
+            pipe(**one[i % 2], **kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(3):
+            pipe(**one[i % 2], **kw)
+        torch.cuda.synchronize()
+        single = dict(frames_per_step=1, ms_per_frame=round((time.perf_counter() - t1) / 3 * 1e3, 2))
+        single["frames_per_s"] = round(1e3 / single["ms_per_frame"], 3)
+
     # ---- roofline leg (after the timed region): HIP events around every MFMA implicit-GEMM launch of one eager frame
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -222,7 +237,7 @@ def main():
                        "frames_per_step_per_gpu": F, "hip_graphs": not args.no_graphs, "parallelism": f"frame-shard x{world}"},
             "frame_tflop_algorithmic": round(TFLOP_PER_FRAME, 2),
             "frame_mfma_frac": round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
-            "roofline": roof, "cpu_baseline": cpu,
+            "single_frame": single, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
