@@ -24,15 +24,22 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TM, int TN, int NST>
+// A_REG: the activation tile goes through registers (global_load_dwordx4 -> ds_write_b128) and only the weight tile by
+// LDS-DMA.  An LDS-DMA wave-instruction costs ~100 issue cycles against ~10 for a register load + 13 for its ds_write,
+// and with both operands on DMA (9 pieces per wave per K-step) the K-loop is DMA-issue-bound (900 vs 640 MFMA cycles);
+// the hybrid issues 5.  Requires NST == 2.
+template <int TM, int TN, int NST, bool A_REG>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 {
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int ROWS = BM + BN;
     constexpr int STAGE = ROWS * 128;
-    constexpr int NGW = ROWS / 32;                    // DMA wave-instructions per wave per stage (8 rows each)
-    static_assert(ROWS % 32 == 0, "rows per stage must split over 4 waves x 8-row pieces");
+    constexpr int NGW = (A_REG ? BN : ROWS) / 32;     // DMA wave-instructions per wave per stage (8 rows each)
+    constexpr int G0 = A_REG ? BM / 8 : 0;            // first DMA piece (pieces below it are the register-staged A rows)
+    constexpr int PA = BM / 32;
+    static_assert(ROWS % 32 == 0 && BN % 32 == 0, "rows per stage must split over 4 waves x 8-row pieces");
+    static_assert(!A_REG || NST == 2, "hybrid staging is double-buffered");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     const int c1_steps = d.C1 >> 6;
 #pragma unroll
     for (int i = 0; i < NGW; ++i) {
-        const int g = wave + 4 * i;
+        const int g = G0 + wave + 4 * i;
         const int row = g * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
         ldsoff[i] = g * 1024;
@@ -93,11 +100,41 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         char* base = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < NGW; ++i) {
-            const bool is_a = (wave + 4 * i) * 8 < BM;                         // wave-uniform
+            const bool is_a = (G0 + wave + 4 * i) * 8 < BM;                    // wave-uniform
             const char* p;
             if (is_a && kt >= c1_steps) p = src2[i] + (long long)(kt - c1_steps) * 128;
             else p = src1[i] + (long long)kt * 128;
             __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + ldsoff[i]), 16, 0, 0);
+        }
+    };
+
+    // register-staged A rows (A_REG): thread -> chunk q of rows r0 + 32 i
+    const int aq = tid & 7, ar0 = tid >> 3;
+    const char* a1[PA];
+    const char* a2[PA];
+    u32x4 ra[PA];
+    if (A_REG) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            int m = m0 + ar0 + 32 * i;
+            m = m < M ? m : M - 1;
+            a1[i] = (const char*)d.x1 + ((long long)m * d.C1 + aq * 8) * 2;
+            a2[i] = d.x2 ? (const char*)d.x2 + ((long long)m * d.C2 + aq * 8) * 2 : nullptr;
+        }
+    }
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const char* p = kt >= c1_steps ? a2[i] + (long long)(kt - c1_steps) * 128 : a1[i] + (long long)kt * 128;
+            ra[i] = *(const u32x4*)p;
+        }
+    };
+    auto store_a = [&](int slot) {
+        char* sA = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = ar0 + 32 * i;
+            *(u32x4*)(sA + r * 128 + ((aq ^ (r & 7)) << 4)) = ra[i];
         }
     };
 
@@ -127,15 +164,36 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     };
 
     // ---- pipeline
+    if (A_REG) {
+        issue_stage(kt_begin, 0);
+        load_a(kt_begin);
+        store_a(0);
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int k = 0; k < nk; ++k) {
+            const bool more = k + 1 < nk;
+            if (more) {
+                issue_stage(kt_begin + k + 1, (k + 1) & 1);      // slot (k+1)&1 was last read in step k-1: free since the barrier
+                load_a(kt_begin + k + 1);
+            }
+            compute(k & 1);
+            if (more) store_a((k + 1) & 1);
+            wait_vmcnt<0>();                                    // this wave's weight pieces of stage k+1 have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and its A rows are written
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s) issue_stage(kt_begin + s, s);
-    for (int k = 0; k < nk; ++k) {
-        wait_vmcnt<NGW * (NST - 2)>();                // this wave's pieces of stage k have landed
-        __builtin_amdgcn_s_barrier();                 // ... and everyone else's; everyone is also done reading stage k-1
-        issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
-        compute(k % NST);
+        for (int s = 0; s < NST - 1; ++s) issue_stage(kt_begin + s, s);
+        for (int k = 0; k < nk; ++k) {
+            wait_vmcnt<NGW * (NST - 2)>();                // this wave's pieces of stage k have landed
+            __builtin_amdgcn_s_barrier();                 // ... and everyone else's; everyone is also done reading stage k-1
+            issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
+            compute(k % NST);
+        }
+        wait_vmcnt<0>();
     }
-    wait_vmcnt<0>();
 
     // ---- epilogue.  bf16 outputs go through LDS so that global stores (and residual loads) are whole 16-byte pieces of
     //      contiguous output rows: the MFMA layout gives each lane 4 channels of one pixel, i.e. 32-byte row fragments
@@ -273,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     }
 }
 
-template <int TM, int TN, int NST>
+template <int TM, int TN, int NST, bool A_REG = false>
 int launch_gemm(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
@@ -281,7 +339,7 @@ int launch_gemm(const dc_conv_desc& d, hipStream_t st)
     const int nblk = dc_cdiv(M, BM) * dc_cdiv(d.Cout, BN);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
     const size_t lds = (size_t)NST * (BM + BN) * 128;
-    auto kern = gemm_dma_kernel<TM, TN, NST>;
+    auto kern = gemm_dma_kernel<TM, TN, NST, A_REG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -311,6 +369,9 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     if (force_small == 1) return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
     if (force_small == 2) return launch_gemm<2, 2, 3>(d, st);
     if (force_small == 3) return launch_gemm<2, 4, 2>(d, st);
+    static const int hybrid = getenv("DC_GEMM_HYBRID") ? atoi(getenv("DC_GEMM_HYBRID")) : 1;
+    if (hybrid && big >= 256) return n160 ? launch_gemm<4, 5, 2, true>(d, st) : launch_gemm<4, 4, 2, true>(d, st);
+    if (hybrid) return n160 ? launch_gemm<2, 5, 2, true>(d, st) : launch_gemm<2, 4, 2, true>(d, st);
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
     if (force_nst == 3 && big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
     if (big >= 256) return n160 ? launch_gemm<4, 5, 2>(d, st) : launch_gemm<4, 4, 2>(d, st);
