@@ -369,7 +369,7 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     if (force_small == 1) return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
     if (force_small == 2) return launch_gemm<2, 2, 3>(d, st);
     if (force_small == 3) return launch_gemm<2, 4, 2>(d, st);
-    static const int hybrid = getenv("DC_GEMM_HYBRID") ? atoi(getenv("DC_GEMM_HYBRID")) : 1;
+    static const int hybrid = getenv("DC_GEMM_HYBRID") ? atoi(getenv("DC_GEMM_HYBRID")) : 0;   // measured: no gain over all-DMA
     if (hybrid && big >= 256) return n160 ? launch_gemm<4, 5, 2, true>(d, st) : launch_gemm<4, 4, 2, true>(d, st);
     if (hybrid) return n160 ? launch_gemm<2, 5, 2, true>(d, st) : launch_gemm<2, 4, 2, true>(d, st);
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
