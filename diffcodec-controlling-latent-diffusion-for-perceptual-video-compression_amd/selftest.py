@@ -1,7 +1,6 @@
-"""Small end-to-end invocation of the hot path used by `__graft_entry__.smoke()` and the GPU tests:
-a reduced-width SD-1.5-shaped model (same topology, block widths (64,128,256,256)) decoding one 256x256 frame,
-checked against the CPU oracle on identical seeded weights / inputs.  The oracle is the checker here, never
-the thing measured."""
+"""Reduced-width SD-1.5-shaped operators (same topology, block widths (64,128,256,256)) for `__graft_entry__.smoke()`
+and the GPU tests, plus the two error metrics they report.  Nothing here touches `oracle/`: the comparison against the
+CPU oracle lives in `__graft_entry__.smoke()` and in `tests/`."""
 import math
 
 import torch
@@ -39,22 +38,3 @@ def psnr(a, b, peak=1.0):
 
 def rel_l2(a, b):
     return (torch.linalg.norm((a.double() - b.double()).flatten()) / torch.linalg.norm(b.double().flatten())).item()
-
-
-def smoke_decode(steps=2, size=256, verbose=True):
-    from oracle import pipeline_ref as R        # checker only
-    pipe, (usd, csd, vsd) = build_small_pipeline()
-    cond, flow = synth_controls(1, size)
-    pe, npe = synth_text(1, dim=SMALL_UNET["cross_attention_dim"])
-    lat = synth_latents(1, size)
-    out = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
-               num_inference_steps=steps, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
-    img = out.images.float().cpu()
-    ref = R.decode_frame(usd, csd, vsd, SMALL_UNET, SMALL_VAE, cond, flow, pe, npe, lat, num_inference_steps=steps,
-                         guidance_scale=4.5, controlnet_conditioning_scale=1.7)
-    p = psnr(img, ref)
-    if verbose:
-        print(f"smoke: {steps}-step decode {size}x{size}: PSNR(hip bf16 vs oracle fp32) = {p:.2f} dB, rel-L2 = {rel_l2(img, ref):.4f}")
-    assert torch.isfinite(img).all()
-    assert p > 30.0, f"smoke decode diverged from the oracle: PSNR {p:.2f} dB"
-    return p
