@@ -237,3 +237,25 @@ def test_full_size_sd15_controlnet_unet_step():
              mid_block_additional_residual=mid, return_dict=False)[0]
     assert tuple(eps.shape) == (2, 4, 64, 64)
     assert T.rel_l2(eps.float().cpu(), re) < 5e-2
+
+
+def test_tiled_decode_config4_layout(small):
+    """§8(f)-2: a 256x448 frame as two full 256x256 windows (x = 0 and 192) through the pipeline, cosine-merged."""
+    T, pipe, _ = small
+    from diffcodec_amd.synthetic import synth_controls, synth_text
+    from diffcodec_amd.tiled_decode import decode_tiled, plan_tiles
+    cond, flow = synth_controls(1, 448)
+    cond, flow = cond[:, :, :256].contiguous(), flow[:, :, :256].contiguous()
+    pe, npe = synth_text(1, dim=T.SMALL_UNET["cross_attention_dim"])
+    lat = torch.randn(1, 4, 32, 56, generator=torch.Generator().manual_seed(1))
+    img, coords = decode_tiled(pipe, cond, flow, pe, npe, tile=256, overlap=64, latents=lat, num_inference_steps=2,
+                               guidance_scale=4.5, controlnet_conditioning_scale=1.7)
+    assert coords == plan_tiles(256, 448, 256, 64) == [(0, 256, 0, 256), (0, 256, 192, 448)]
+    assert img.shape == (256, 448, 3) and img.dtype.name == "uint8"
+    # left tile alone == the plain single-frame decode of that window (same noise window)
+    one = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond[..., :256].contiguous(), flow_cond=flow[..., :256].contiguous(),
+               latents=lat[..., :32].contiguous(), num_inference_steps=2, guidance_scale=4.5, controlnet_conditioning_scale=1.7,
+               output_type="np").images[0]
+    a = torch.from_numpy(img[8:-8, 8:150].astype("float32") / 255)
+    b = torch.from_numpy((one[8:-8, 8:150] * 255).astype("uint8").astype("float32") / 255)
+    assert T.psnr(a, b) > 35.0

@@ -111,3 +111,29 @@ def test_latent_merge_partition_and_coordinate_quirk():
     inner = (w[:, None] * w[None, :]) > 1e-6
     m = inner.repeat(2, 2)                                                          # Hann is 0 on each tile's border
     assert torch.allclose(merged[0, :, m], lat[0, :, m], atol=1e-5)
+
+
+def test_plan_tiles_full_windows_cover_the_frame():
+    from diffcodec_amd.tiled_decode import plan_tiles
+    assert plan_tiles(512, 960, 512, 64) == [(0, 512, 0, 512), (0, 512, 448, 960)]          # config 4: two tiles, x = 0 and 448
+    c = plan_tiles(1080, 1920, 512, 64)
+    assert all(y2 - y1 == 512 and x2 - x1 == 512 for y1, y2, x1, x2 in c)                    # no undersized edge tiles
+    cover = np.zeros((1080, 1920), np.int32)
+    for y1, y2, x1, x2 in c:
+        cover[y1:y2, x1:x2] += 1
+    assert cover.min() >= 1 and max(y2 for _, y2, _, _ in c) == 1080 and max(x2 for *_, x2 in c) == 1920
+    assert len(plan_tiles(1024, 1024, 512, 0)) == 4                                          # config 5: 4 x 512 patches
+    with pytest.raises(ValueError):
+        plan_tiles(256, 1024, 512, 64)
+
+
+def test_package_never_imports_the_oracle():
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "diffcodec-controlling-latent-diffusion-for-perceptual-video-compression_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "oracle/" not in src or f == "selftest.py", f
