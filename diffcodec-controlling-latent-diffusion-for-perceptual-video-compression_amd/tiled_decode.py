@@ -6,7 +6,8 @@ run; its edge tiles are undersized (128 px), which the model cannot take (flowne
 Policy here (documented deviation): every tile is a full `tile` x `tile` window and the last row/column of windows is
 shifted inward to end at the frame border, so overlaps grow at the border instead of tiles shrinking.  Tiles of all
 frames are independent decode units: they are batched through the pipeline `batch` at a time (and are what
-`sharding.shard_units` deals across GPUs for config 5).  Blending: `tiling.merge_costiles` (raised-cosine feather)."""
+`sharding.shard_units` deals across GPUs for config 5).  Blending: `tiling.merge_ramp` (half-cosine ramps on inner
+edges only; the reference's `merge_costiles` window zeroes lines inside every tile and is kept only for parity)."""
 import numpy as np
 import torch
 
@@ -50,4 +51,4 @@ def decode_tiled(pipe, controlnet_cond, flow_cond, prompt_embeds, negative_promp
         out = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cc, flow_cond=fc, latents=lt,
                    output_type="np", **pipe_kwargs).images                                   # [n, tile, tile, 3] in [0,1]
         tiles_out += [np.asarray(o * 255.0, np.float32) for o in out]
-    return tiling.merge_costiles(tiles_out, coords, (h, w), order="hwc", feather=overlap if feather is None else feather), coords
+    return tiling.merge_ramp(tiles_out, coords, (h, w), order="hwc", feather=overlap if feather is None else feather), coords

@@ -89,6 +89,39 @@ def merge_costiles(tiles, coords, full_shape, order="hwc", feather=64):
     return _accumulate(tiles, coords, full_shape, order, mask)
 
 
+def merge_ramp(tiles, coords, full_shape, order="hwc", feather=64):
+    """Blend used by this package's tiled-decode driver (NOT a reference function): half-cosine ramps 0 -> 1 over
+    `feather` pixels, applied only on tile edges that lie inside the frame (edges on the frame border keep weight 1), so
+    weights sum to a strictly positive value everywhere.  `merge_costiles` above keeps the reference's arithmetic, whose
+    window (a full 0->1->0 hump per edge) blacks out lines f-1 pixels from every tile edge."""
+    h, w = full_shape
+
+    def ramp(n, lo_inner, hi_inner):
+        wv = np.ones(n, np.float32)
+        f = min(feather, n // 2)
+        if f > 0:
+            r = (0.5 - 0.5 * np.cos(np.pi * (np.arange(f, dtype=np.float32) + 0.5) / f)).astype(np.float32)
+            if lo_inner:
+                wv[:f] = r
+            if hi_inner:
+                wv[-f:] = r[::-1]
+        return wv
+
+    c = tiles[0].shape[2] if order == "hwc" else tiles[0].shape[0]
+    shape = (h, w, c) if order == "hwc" else (c, h, w)
+    out, weight = np.zeros(shape, np.float32), np.zeros(shape, np.float32)
+    for tile, (y1, y2, x1, x2) in zip(tiles, coords):
+        m2 = np.outer(ramp(y2 - y1, y1 > 0, y2 < h), ramp(x2 - x1, x1 > 0, x2 < w))
+        tile = _fit(tile, y2 - y1, x2 - x1, order)
+        if order == "hwc":
+            out[y1:y2, x1:x2, :] += tile.astype(np.float32) * m2[:, :, None]
+            weight[y1:y2, x1:x2, :] += m2[:, :, None]
+        else:
+            out[:, y1:y2, x1:x2] += tile.astype(np.float32) * m2[None]
+            weight[:, y1:y2, x1:x2] += m2[None]
+    return np.clip(np.rint(out / weight), 0, 255).astype(np.uint8)
+
+
 def merge_latent_tiles_from_pixel_coords(latents, pixel_coords, full_latent_shape, original_image_size, eps: float = 1e-8):
     assert len(latents) == len(pixel_coords), "latents and coords length mismatch"
     device, dtype = latents[0].device, latents[0].dtype

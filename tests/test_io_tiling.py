@@ -113,6 +113,16 @@ def test_latent_merge_partition_and_coordinate_quirk():
     assert torch.allclose(merged[0, :, m], lat[0, :, m], atol=1e-5)
 
 
+def test_merge_ramp_is_a_partition_of_unity_everywhere():
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 255, (96, 130, 3)).astype(np.float32)
+    from diffcodec_amd.tiled_decode import plan_tiles
+    coords = plan_tiles(96, 130, 64, 16)
+    tiles = [img[y1:y2, x1:x2] for y1, y2, x1, x2 in coords]
+    out = T.merge_ramp(tiles, coords, (96, 130), "hwc", feather=16)
+    assert np.array_equal(out, img.astype(np.uint8))                        # consistent tiles reproduce the frame exactly
+
+
 def test_plan_tiles_full_windows_cover_the_frame():
     from diffcodec_amd.tiled_decode import plan_tiles
     assert plan_tiles(512, 960, 512, 64) == [(0, 512, 0, 512), (0, 512, 448, 960)]          # config 4: two tiles, x = 0 and 448
