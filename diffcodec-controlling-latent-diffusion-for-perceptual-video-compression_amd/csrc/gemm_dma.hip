@@ -13,6 +13,22 @@
 #include "../../include/diffcodec_hip.h"
 #include <cstdlib>
 
+// Developer-only phase stamps (tools/gemm_stamp.py builds this file with -DDC_STAMP into a scratch .so): s_memtime at
+// kernel entry / after the first stage landed / after the K loop / at exit, written to the (otherwise unused) split-K
+// workspace.  Never defined in the product build.
+#ifdef DC_STAMP
+#define DC_STAMP_AT(i)                                                                         \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && d.splitk_ws) {                                                 \
+            unsigned long long t_;                                                             \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            ((unsigned long long*)d.splitk_ws)[(long long)blockIdx.x * 4 + (i)] = t_;          \
+        }                                                                                      \
+    } while (0)
+#else
+#define DC_STAMP_AT(i)
+#endif
+
 namespace {
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -46,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 15, fq = lane >> 4;
+    DC_STAMP_AT(0);
 
     const int HoWo = d.Ho * d.Wo;
     const int M = d.N * HoWo;
@@ -189,11 +206,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         for (int k = 0; k < nk; ++k) {
             wait_vmcnt<NGW * (NST - 2)>();                // this wave's pieces of stage k have landed
             __builtin_amdgcn_s_barrier();                 // ... and everyone else's; everyone is also done reading stage k-1
+            if (k == 0) DC_STAMP_AT(1);
             issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
             compute(k % NST);
         }
         wait_vmcnt<0>();
     }
+    DC_STAMP_AT(2);
 
     // ---- epilogue.  bf16 outputs go through LDS so that global stores (and residual loads) are whole 16-byte pieces of
     //      contiguous output rows: the MFMA layout gives each lane 4 channels of one pixel, i.e. 32-byte row fragments
@@ -267,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             const int m = m0 + row, c = col0 + pc * 8;
             if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
         }
+        DC_STAMP_AT(3);
         return;
     }
     // ---- direct epilogue (fp32 outputs, split-K partials): same contract as igemm.hip
