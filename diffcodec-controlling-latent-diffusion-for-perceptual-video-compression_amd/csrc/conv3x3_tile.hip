@@ -230,33 +230,58 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
     wait_vmcnt<0>();
 
-    // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3]
+    // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3].  Bias / time-embedding row / residual are all
+    //      fetched before the arithmetic so the loads overlap instead of forming a chain of dependent L2 round trips.
+    f32x4 bv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (d.splitk <= 1 && nb < d.Cout) {
+            if (d.bias) v = *(const f32x4*)(d.bias + nb);
+            if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)n_img * d.row_add_stride + nb);
+        }
+        bv[tn] = v;
+    }
+    long long mrow[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         const int oy = oy0 + ((wm * TM + tm) << sh) + fdy, ox = ox0 + fdx;
-        const long long m = ((long long)n_img * d.Ho + oy) * d.Wo + ox;
+        mrow[tm] = ((long long)n_img * d.Ho + oy) * d.Wo + ox;
+    }
+    bf16x4 rr[TM][TN];
+    if (d.residual && d.splitk <= 1) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+                rr[tm][tn] = nb < d.Cout ? *(const bf16x4*)((const bf16_t*)d.residual + mrow[tm] * d.Cout + nb)
+                                         : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
             if (nb >= d.Cout) continue;
             f32x4 v = acc[tn][tm];
-            const long long off = m * d.Cout + nb;
+            const long long off = mrow[tm] * d.Cout + nb;
             if (d.splitk > 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(d.splitk_ws + off + r, v[r]);
                 continue;
             }
-            if (d.bias) v += *(const f32x4*)(d.bias + nb);
-            if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)n_img * d.row_add_stride + nb);
+            v += bv[tn];
             if (d.act == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
             }
             v *= d.out_scale;
             if (d.residual) {
-                const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
             }
             if (d.out_f32) {
                 *(f32x4*)((float*)d.out + off) = v;

@@ -224,6 +224,27 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         static_assert(BM * PITCH <= NST * STAGE, "output tile must fit in the stage buffers");
         __syncthreads();                                        // all waves are done reading the last stage
         const int ocols = d.epilogue == 1 ? OC / 2 : OC;
+        // all epilogue operands are fetched up front (independent loads in flight together): issued one (tm, tn) tile at
+        // a time behind `if (bias)` / `if (residual)` they serialise into ~20 dependent L2 round trips per workgroup
+        f32x4 bv[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+            bv[tn] = (d.bias && nb < d.Cout) ? *(const f32x4*)(d.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        bf16x4 rr[TM][TN];
+        if (d.residual && d.epilogue == 0) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int m = m0 + (wm * TM + tm) * 16 + fr;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+                    rr[tm][tn] = (m < M && nb < d.Cout) ? *(const bf16x4*)((const bf16_t*)d.residual + (long long)m * d.Cout + nb)
+                                                        : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                }
+            }
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int row = (wm * TM + tm) * 16 + fr;
@@ -232,13 +253,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             if (d.epilogue == 1) {
 #pragma unroll
                 for (int tp = 0; tp < TN / 2; ++tp) {
-                    const int nb = n0 + (wn * TN + 2 * tp) * 16 + 4 * fq;
-                    f32x4 h = acc[2 * tp][tm];
-                    f32x4 g = acc[2 * tp + 1][tm];
-                    if (d.bias && nb < d.Cout) {
-                        h += *(const f32x4*)(d.bias + nb);
-                        g += *(const f32x4*)(d.bias + nb + 16);
-                    }
+                    const f32x4 h = acc[2 * tp][tm] + bv[2 * tp];
+                    const f32x4 g = acc[2 * tp + 1][tm] + bv[2 * tp + 1];
                     bf16x4 pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
@@ -249,24 +265,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 for (int tn = 0; tn < TN; ++tn) {
                     const int nl = (wn * TN + tn) * 16 + 4 * fq;
                     const int nb = n0 + nl;
-                    f32x4 v = acc[tn][tm];
-                    if (nb < d.Cout) {
-                        if (d.bias) v += *(const f32x4*)(d.bias + nb);
-                        if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-                    }
+                    f32x4 v = acc[tn][tm] + bv[tn];
+                    if (d.row_add && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
                     if (d.act == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
                     }
                     v *= d.out_scale;
-                    if (d.residual) {                           // keep fp32 until the residual is added: stage as fp32? no —
-                        // the residual is added in the store pass below on the bf16-rounded product, which would round twice;
-                        // instead fetch it here (8-byte loads) only when present
-                        if (m < M && nb < d.Cout) {
-                            const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + (long long)m * d.Cout + nb);
+                    if (d.residual) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                        }
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
                     }
                     bf16x4 pk;
 #pragma unroll
