@@ -22,7 +22,7 @@
         if (threadIdx.x == 0 && d.splitk_ws) {                                                 \
             unsigned long long t_;                                                             \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
-            ((unsigned long long*)d.splitk_ws)[(long long)blockIdx.x * 4 + (i)] = t_;          \
+            ((unsigned long long*)d.splitk_ws)[(long long)blockIdx.x * 8 + (i)] = t_;          \
         }                                                                                      \
     } while (0)
 #else
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         constexpr int PITCH = OC * 2 + 16;                      // bytes per staged row (+16: spread rows over banks)
         static_assert(BM * PITCH <= NST * STAGE, "output tile must fit in the stage buffers");
         __syncthreads();                                        // all waves are done reading the last stage
+        DC_STAMP_AT(4);
         const int ocols = d.epilogue == 1 ? OC / 2 : OC;
         // all epilogue operands are fetched up front (independent loads in flight together): issued one (tm, tn) tile at
         // a time behind `if (bias)` / `if (residual)` they serialise into ~20 dependent L2 round trips per workgroup
@@ -283,7 +284,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 }
             }
         }
+        DC_STAMP_AT(5);
         __syncthreads();
+        DC_STAMP_AT(6);
         // cooperative store: consecutive lanes -> consecutive 16-byte pieces of one output row
         const int out_cols = d.epilogue == 1 ? d.Cout >> 1 : d.Cout;
         const int col0 = d.epilogue == 1 ? n0 >> 1 : n0;

@@ -20,14 +20,16 @@ pc = ops.PackedConv(torch.randn(cout, c, 1, 1, generator=g) / math.sqrt(c), torc
 out = torch.empty(n, h, h, cout, device="cuda", dtype=torch.bfloat16)
 m = n * h * h
 nblk = math.ceil(m / 128) * math.ceil(cout / 160)
-ws = torch.zeros(nblk * 4, device="cuda", dtype=torch.int64)
+ws = torch.zeros(nblk * 8, device="cuda", dtype=torch.int64)
 d = lib.ConvDesc(x1=x.data_ptr(), x2=0, w=pc.w.data_ptr(), bias=pc.bias.data_ptr(), gn_ab=0, row_add=0, residual=0, out=out.data_ptr(),
                  splitk_ws=ws.data_ptr(), N=n, H=h, W=h, C1=c, C2=0, Cout=cout, ksize=1, stride=1, pad=1, upsample=0, Ho=h, Wo=h,
                  gn_silu=0, epilogue=0, out_f32=0, out_scale=1.0, splitk=1, gn_batch=0, act=0, row_add_stride=0)
 for _ in range(3):
     assert L.dc_conv_igemm_bf16(ctypes.byref(d), torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
-t = ws.view(nblk, 4).cpu().double()
-ph = torch.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0]], 1)
-print("workgroups", nblk, " median cycles: prologue(first stage) %.0f | K loop %.0f | epilogue %.0f | total %.0f" % tuple(ph.median(0).values.tolist()))
+t = ws.view(nblk, 8).cpu().double()
+ph = torch.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 3] - t[:, 0], t[:, 4] - t[:, 2], t[:, 5] - t[:, 4],
+                  t[:, 6] - t[:, 5], t[:, 3] - t[:, 6]], 1)
+print("workgroups", nblk, " median cycles: prologue(first stage) %.0f | K loop %.0f | epilogue %.0f | total %.0f\n   epilogue parts: barrier-in %.0f | "
+      "operand loads + math + ds_write %.0f | barrier-mid %.0f | row stores %.0f" % tuple(ph.median(0).values.tolist()))
 print("kernel span (cycles): %.0f" % (t[:, 3].max() - t[:, 0].min()).item())
