@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         }
     };
 
+    // bias for this lane's output channels: fetched now so its latency hides under the K loop
+    f32x4 bv[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+        bv[tn] = (d.bias && nb < d.Cout) ? *(const f32x4*)(d.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
     // ---- pipeline
     if (A_REG) {
         issue_stage(kt_begin, 0);
@@ -227,12 +235,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         const int ocols = d.epilogue == 1 ? OC / 2 : OC;
         // all epilogue operands are fetched up front (independent loads in flight together): issued one (tm, tn) tile at
         // a time behind `if (bias)` / `if (residual)` they serialise into ~20 dependent L2 round trips per workgroup
-        f32x4 bv[TN];
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
-            bv[tn] = (d.bias && nb < d.Cout) ? *(const f32x4*)(d.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
         bf16x4 rr[TM][TN];
         if (d.residual && d.epilogue == 0) {
 #pragma unroll
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         for (int tm = 0; tm < TM; ++tm) {
             const int row = (wm * TM + tm) * 16 + fr;
             const int m = m0 + row;
-            const int nimg = (m < M ? m : M - 1) / HoWo;
+            const int nimg = d.row_add ? (m < M ? m : M - 1) / HoWo : 0;
             if (d.epilogue == 1) {
 #pragma unroll
                 for (int tp = 0; tp < TN / 2; ++tp) {
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
                     }
-                    v *= d.out_scale;
+                    if (d.out_scale != 1.0f) v *= d.out_scale;
                     if (d.residual) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
