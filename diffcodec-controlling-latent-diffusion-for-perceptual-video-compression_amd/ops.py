@@ -167,7 +167,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
 # GroupNorm+SiLU in front of a conv: folded into the conv's load stage only when the conv has a single output-channel
 # tile (Cout <= 160).  With more N-tiles every workgroup of a pixel tile would redo the same exp/rcp work (Cout/160 x
 # the 1.4x halo overlap); one HBM-bound elementwise pass (which also resolves the skip concat) is cheaper.
-FUSE_GN_MAX_COUT = 160
+FUSE_GN_MAX_COUT = int(__import__("os").environ.get("DC_FUSE_GN_MAX_COUT", "160"))
 
 
 def conv_gn_silu(x, pc, ab, x2=None, **kw):
