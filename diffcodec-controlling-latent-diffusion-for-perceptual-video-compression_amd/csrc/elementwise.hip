@@ -113,6 +113,61 @@ __global__ void postprocess_kernel(const float* __restrict__ x, float* __restric
     }
 }
 
+// FreeU (validation.py:106 -> diffusers apply_freeu / fourier_filter [recalled]): the skip feature's four lowest
+// frequency bins (k in {0,-1}^2 of the 2-D DFT, i.e. the 2x2 centre block after fftshift) are scaled by `s`, everything
+// else is kept.  Four DFT coefficients need no FFT: seven real sums per (sample, channel), then
+//   y = x + (s-1)/(HW) * Re sum_k X[k] e^{+i k.phi}.   One thread per (sample, channel); maps are 8x8 / 16x16.
+__global__ void freeu_lowfreq_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C, float s)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const bf16_t* xp = x + (long long)n * H * W * C + c;
+    bf16_t* yp = y + (long long)n * H * W * C + c;
+    const float wy = 6.283185307179586f / (float)H, wx = 6.283185307179586f / (float)W;
+    float a = 0.f, cx = 0.f, sx = 0.f, cy = 0.f, sy = 0.f, cxy = 0.f, sxy = 0.f;
+    for (int py = 0; py < H; ++py) {
+        float syv, cyv;
+        __sincosf(wy * (float)py, &syv, &cyv);
+        for (int px = 0; px < W; ++px) {
+            float sxv, cxv;
+            __sincosf(wx * (float)px, &sxv, &cxv);
+            const float v = (float)xp[((long long)py * W + px) * C];
+            a += v;
+            cx += v * cxv;
+            sx += v * sxv;
+            cy += v * cyv;
+            sy += v * syv;
+            cxy += v * (cxv * cyv - sxv * syv);        // cos(phi_x + phi_y)
+            sxy += v * (sxv * cyv + cxv * syv);        // sin(phi_x + phi_y)
+        }
+    }
+    const float g = (s - 1.0f) / (float)(H * W);
+    for (int py = 0; py < H; ++py) {
+        float syv, cyv;
+        __sincosf(wy * (float)py, &syv, &cyv);
+        for (int px = 0; px < W; ++px) {
+            float sxv, cxv;
+            __sincosf(wx * (float)px, &sxv, &cxv);
+            const long long o = ((long long)py * W + px) * C;
+            const float low = a + cx * cxv + sx * sxv + cy * cyv + sy * syv + cxy * (cxv * cyv - sxv * syv) + sxy * (sxv * cyv + cxv * syv);
+            yp[o] = (bf16_t)((float)xp[o] + g * low);
+        }
+    }
+}
+// FreeU backbone scaling: hidden[:, :C/2] *= b  (NHWC: the first half of every pixel's channels)
+__global__ void freeu_backbone_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int C, float b, long long nvec)
+{
+    const int nv = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % nv) * 8;
+        const bf16x8 v = *(const bf16x8*)(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c + j) < C / 2 ? (bf16_t)((float)v[j] * b) : v[j];
+        *(bf16x8*)(y + i * 8) = o;
+    }
+}
 __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ d, int R, int C)
 {
     __shared__ bf16_t tile[32][33];
@@ -193,6 +248,20 @@ extern "C" int dc_timestep_embedding_f32(const float* t_dev, const int* step_dev
 {
     if (!t_dev || !out || n <= 0 || dim <= 0 || (dim & 1)) return DC_ERR_INVALID;
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3(dc_cdiv((long long)n * dim / 2, 256)), dim3(256), 0, (hipStream_t)stream, t_dev, step_dev, out, n, dim);
+    return dc_launch_status();
+}
+extern "C" int dc_freeu_lowfreq_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, float s, void* stream)
+{
+    if (!x || !y || N <= 0 || H <= 1 || W <= 1 || C <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(freeu_lowfreq_kernel, dim3(dc_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, N, H, W, C, s);
+    return dc_launch_status();
+}
+extern "C" int dc_freeu_backbone_nhwc_bf16(const void* x, void* y, long long pixels, int C, float b, void* stream)
+{
+    if (!x || !y || pixels <= 0 || C <= 0 || (C & 15)) return DC_ERR_INVALID;
+    const long long nvec = pixels * (C >> 3);
+    hipLaunchKernelGGL(freeu_backbone_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, C, b, nvec);
     return dc_launch_status();
 }
 extern "C" int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream)

@@ -50,6 +50,8 @@ SIGNATURES = {
     "dc_attention_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp],
     "dc_softmax_rows_f32_to_bf16": [vp, vp, i64, i32, f32, vp],
     "dc_timestep_embedding_f32": [vp, vp, vp, i32, i32, vp],
+    "dc_freeu_lowfreq_nhwc_bf16": [vp, vp, i32, i32, i32, i32, f32, vp],
+    "dc_freeu_backbone_nhwc_bf16": [vp, vp, i64, i32, f32, vp],
     "dc_transpose_bf16": [vp, vp, i32, i32, i32, vp],
     "dc_vae_sample_latents": [vp, vp, vp, f32, i32, i32, i32, i32, vp],
     "dc_silu_f32": [vp, vp, i64, vp],

@@ -330,6 +330,22 @@ def timestep_embedding(t_dev, n, dim, step_dev=None):
     return out
 
 
+def freeu_lowfreq(x, s):
+    _chk(x, BF16, "x")
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    lib.call("dc_freeu_lowfreq_nhwc_bf16", x.data_ptr(), y.data_ptr(), n, h, w, c, float(s), _stream())
+    return y
+
+
+def freeu_backbone(x, b):
+    _chk(x, BF16, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    lib.call("dc_freeu_backbone_nhwc_bf16", x.data_ptr(), y.data_ptr(), x.numel() // c, c, float(b), _stream())
+    return y
+
+
 def transpose_bf16(x):
     """[B,R,C] -> [B,C,R]"""
     _chk(x, BF16, "x")

@@ -79,8 +79,16 @@ class StableDiffusionDualFlowControlNetPipeline:
     def enable_xformers_memory_efficient_attention(self):       # pipeline.py:138-142 — attention is already fused
         return None
 
-    def enable_freeu(self, *a, **k):
-        raise NotImplementedError("FreeU (validation.py:106) is not implemented yet — see DESIGN.md 'next'")
+    def enable_freeu(self, s1, s2, b1, b2):
+        """validation.py:106 `pipe.enable_freeu(s1=0.9, s2=0.2, b1=1.2, b2=1.4)` -> UNet.enable_freeu."""
+        if not hasattr(self.unet, "enable_freeu"):
+            raise ValueError("The pipeline must have `unet` for using FreeU.")
+        self.unet.enable_freeu(s1, s2, b1, b2)
+        self._graphs.clear()
+
+    def disable_freeu(self):
+        self.unet.disable_freeu()
+        self._graphs.clear()
 
     def enable_hip_graphs(self, flag=True):
         self._use_graphs = bool(flag)

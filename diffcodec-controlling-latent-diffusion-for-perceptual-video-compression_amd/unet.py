@@ -54,6 +54,13 @@ class HipUNet2DConditionModel:
         self.norm_out = (sd["conv_norm_out.weight"].float().to(device), sd["conv_norm_out.bias"].float().to(device))
         self.conv_out = PackedConv(sd["conv_out.weight"], sd["conv_out.bias"], device)
         self._ctx_key = None
+        self.freeu = None                      # dict(s1, s2, b1, b2) when enabled (diffusers UNet.enable_freeu)
+
+    def enable_freeu(self, s1, s2, b1, b2):
+        self.freeu = dict(s1=float(s1), s2=float(s2), b1=float(b1), b2=float(b2))
+
+    def disable_freeu(self):
+        self.freeu = None
 
     # ---- reference-compatible niceties
     def to(self, *a, **k):
@@ -93,9 +100,13 @@ class HipUNet2DConditionModel:
         sample = enc.run_mid(sample, temb)
         if mid_res is not None:
             sample = ops.add_bf16(sample, mid_res)
-        for blk in self.up:
+        for bi, blk in enumerate(self.up):
             for r, a in zip(blk["resnets"], blk["attns"]):
-                sample = r(sample, temb, x2=res.pop())                         # cat[sample, skip] read in place
+                skip = res.pop()
+                if self.freeu is not None and bi < 2:                          # apply_freeu: resolution_idx 0 and 1 only
+                    sample = ops.freeu_backbone(sample, self.freeu["b1" if bi == 0 else "b2"])
+                    skip = ops.freeu_lowfreq(skip, self.freeu["s1" if bi == 0 else "s2"])
+                sample = r(sample, temb, x2=skip)                              # cat[sample, skip] read in place
                 if a is not None:
                     sample = a(sample)
             if blk["up"] is not None:

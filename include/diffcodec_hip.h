@@ -143,6 +143,10 @@ int dc_softmax_rows_f32_to_bf16(const float* s, void* p, long long rows, int col
 /* time_proj — flownet.py:74: sinusoidal embedding of the timestep t_dev[step_dev ? *step_dev : 0] (device-resident so
  * that a captured hipGraph of one denoising step can be replayed for every step). */
 int dc_timestep_embedding_f32(const float* t_dev, const int* step_dev, float* out, int n, int dim, void* stream);
+/* FreeU — pipe.enable_freeu(s1,s2,b1,b2) (validation.py:106) -> diffusers apply_freeu [recalled]: skip features of up-blocks
+ * 0/1 get their 2x2 lowest-frequency block scaled by s (fourier_filter, threshold 1); the backbone's first C/2 channels get *b. */
+int dc_freeu_lowfreq_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, float s, void* stream);
+int dc_freeu_backbone_nhwc_bf16(const void* x, void* y, long long pixels, int C, float b, void* stream);
 /* dst[c][r] = src[r][c], bf16, batch of `batch` matrices (VAE attention: V -> V^T). */
 int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream);
 /* DiagonalGaussianDistribution.sample() * scale — train_controlnet.py:1081, pipeline.ipynb cell 7:

@@ -119,7 +119,26 @@ def _mid_block(sd, cfg, sample, emb, ctx):
     return resnet(sd, "mid_block.resnets.1.", sample, emb, g, 1e-5)
 
 
-def unet_forward(sd, cfg, sample, t, ctx, down_res=None, mid_res=None):
+def fourier_filter(x, threshold, scale):
+    """diffusers.utils.torch_utils.fourier_filter [recalled]: scale the centred (2*threshold)^2 low-frequency block."""
+    xf = torch.fft.fftshift(torch.fft.fftn(x.float(), dim=(-2, -1)), dim=(-2, -1))
+    h, w = x.shape[-2:]
+    mask = torch.ones_like(xf.real)
+    mask[..., h // 2 - threshold:h // 2 + threshold, w // 2 - threshold:w // 2 + threshold] = scale
+    return torch.fft.ifftn(torch.fft.ifftshift(xf * mask, dim=(-2, -1)), dim=(-2, -1)).real
+
+
+def apply_freeu(resolution_idx, hidden, res_hidden, s1, s2, b1, b2):
+    """diffusers.utils.torch_utils.apply_freeu [recalled] (enabled at validation.py:106)."""
+    if resolution_idx in (0, 1):
+        b, s = (b1, s1) if resolution_idx == 0 else (b2, s2)
+        half = hidden.shape[1] // 2
+        hidden = torch.cat([hidden[:, :half] * b, hidden[:, half:]], 1)
+        res_hidden = fourier_filter(res_hidden, 1, s)
+    return hidden, res_hidden
+
+
+def unet_forward(sd, cfg, sample, t, ctx, down_res=None, mid_res=None, freeu=None):
     """UNet2DConditionModel.forward as called at pipeline.py:358-367 [recalled topology]."""
     boc = cfg["block_out_channels"]
     g = cfg["groups"]
@@ -135,7 +154,10 @@ def unet_forward(sd, cfg, sample, t, ctx, down_res=None, mid_res=None):
     for i in range(nb):
         cross = cfg["down_cross"][nb - 1 - i]
         for j in range(cfg["layers_per_block"] + 1):
-            sample = torch.cat([sample, res.pop()], dim=1)
+            skip = res.pop()
+            if freeu is not None:
+                sample, skip = apply_freeu(i, sample, skip, **freeu)
+            sample = torch.cat([sample, skip], dim=1)
             sample = resnet(sd, f"up_blocks.{i}.resnets.{j}.", sample, emb, g, 1e-5)
             if cross:
                 sample = transformer(sd, f"up_blocks.{i}.attentions.{j}.", sample, ctx, cfg["num_heads"], g)

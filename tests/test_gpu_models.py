@@ -259,3 +259,29 @@ def test_tiled_decode_config4_layout(small):
     a = torch.from_numpy(img[8:-8, 8:150].astype("float32") / 255)
     b = torch.from_numpy((one[8:-8, 8:150] * 255).astype("uint8").astype("float32") / 255)
     assert T.psnr(a, b) > 35.0
+
+
+def test_freeu_matches_fft_restatement(small):
+    """§8(f)-3: FreeU (validation.py:106).  Kernel-level: the 4-bin direct DFT == torch.fft fourier_filter; model-level:
+    UNet forward with FreeU enabled vs the oracle's restatement.  diffusers semantics recalled -> parity unpinned."""
+    T, pipe, (usd, csd, vsd) = small
+    from diffcodec_amd import ops
+    from oracle import sd15_ref as M
+    g = torch.Generator().manual_seed(21)
+    for (n, c, hw) in [(2, 64, 8), (1, 48, 16)]:
+        x = torch.randn(n, c, hw, hw, generator=g).to(torch.bfloat16).float()
+        ref = M.fourier_filter(x, 1, 0.2)
+        out = ops.freeu_lowfreq(x.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16), 0.2).float().cpu().permute(0, 3, 1, 2)
+        torch.testing.assert_close(out, ref, rtol=2e-2, atol=2e-2)
+    cond, flow, pe, npe, lat = _inputs(T)
+    ctx, x = torch.cat([npe, pe], 0), torch.cat([lat, lat], 0)
+    fu = dict(s1=0.9, s2=0.2, b1=1.2, b2=1.4)
+    ref = M.unet_forward(usd, T.SMALL_UNET, x, 501, ctx, freeu=fu)
+    ref_plain = M.unet_forward(usd, T.SMALL_UNET, x, 501, ctx)
+    pipe.enable_freeu(**fu)
+    try:
+        eps = pipe.unet(x.to(DEV), 501, encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].float().cpu()
+    finally:
+        pipe.disable_freeu()
+    assert T.rel_l2(eps, ref) < 4e-2
+    assert T.rel_l2(ref_plain, ref) > 3 * T.rel_l2(eps, ref)          # FreeU really changes the output, and we follow it
