@@ -168,6 +168,19 @@ __global__ void freeu_backbone_kernel(const bf16_t* __restrict__ x, bf16_t* __re
         *(bf16x8*)(y + i * 8) = o;
     }
 }
+// y = a*x0 + b*x1 + c*x2 + d*x3 (fp32; null pointers skipped) — scheduler state updates (UniPC predictor / corrector,
+// epsilon -> x0 conversion, CFG combine in the generic loop: pipeline.py:370-375)
+__global__ void lincomb4_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ x2,
+                                const float* __restrict__ x3, float a, float b, float c, float d, float* __restrict__ y, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = a * x0[i];
+        if (x1) v += b * x1[i];
+        if (x2) v += c * x2[i];
+        if (x3) v += d * x3[i];
+        y[i] = v;
+    }
+}
 __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ d, int R, int C)
 {
     __shared__ bf16_t tile[32][33];
@@ -262,6 +275,13 @@ extern "C" int dc_freeu_backbone_nhwc_bf16(const void* x, void* y, long long pix
     if (!x || !y || pixels <= 0 || C <= 0 || (C & 15)) return DC_ERR_INVALID;
     const long long nvec = pixels * (C >> 3);
     hipLaunchKernelGGL(freeu_backbone_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, C, b, nvec);
+    return dc_launch_status();
+}
+extern "C" int dc_lincomb4_f32(const float* x0, const float* x1, const float* x2, const float* x3, float a, float b, float c,
+                               float d, float* y, long long n, void* stream)
+{
+    if (!x0 || !y || n <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(lincomb4_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x0, x1, x2, x3, a, b, c, d, y, n);
     return dc_launch_status();
 }
 extern "C" int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream)

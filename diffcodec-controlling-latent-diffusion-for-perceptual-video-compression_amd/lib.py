@@ -52,6 +52,7 @@ SIGNATURES = {
     "dc_timestep_embedding_f32": [vp, vp, vp, i32, i32, vp],
     "dc_freeu_lowfreq_nhwc_bf16": [vp, vp, i32, i32, i32, i32, f32, vp],
     "dc_freeu_backbone_nhwc_bf16": [vp, vp, i64, i32, f32, vp],
+    "dc_lincomb4_f32": [vp, vp, vp, vp, f32, f32, f32, f32, vp, i64, vp],
     "dc_transpose_bf16": [vp, vp, i32, i32, i32, vp],
     "dc_vae_sample_latents": [vp, vp, vp, f32, i32, i32, i32, i32, vp],
     "dc_silu_f32": [vp, vp, i64, vp],

@@ -346,6 +346,19 @@ def freeu_backbone(x, b):
     return y
 
 
+def lincomb(terms):
+    """sum_i coef_i * tensor_i over up to four same-shaped contiguous fp32 device tensors: [(coef, tensor), ...]."""
+    terms = [(float(c), t) for c, t in terms if t is not None]
+    assert 1 <= len(terms) <= 4
+    for _, t in terms:
+        _chk(t, F32, "term")
+    y = torch.empty_like(terms[0][1])
+    pad = terms + [(0.0, None)] * (4 - len(terms))
+    lib.call("dc_lincomb4_f32", pad[0][1].data_ptr(), _ptr(pad[1][1]), _ptr(pad[2][1]), _ptr(pad[3][1]), pad[0][0], pad[1][0],
+             pad[2][0], pad[3][0], y.data_ptr(), y.numel(), _stream())
+    return y
+
+
 def transpose_bf16(x):
     """[B,R,C] -> [B,C,R]"""
     _chk(x, BF16, "x")

@@ -269,9 +269,9 @@ class StableDiffusionDualFlowControlNetPipeline:
                 mid = torch.cat([torch.zeros_like(mid), mid], 0)
             noise_pred = self.unet(x_in, t, encoder_hidden_states=text, timestep_cond=None, cross_attention_kwargs=None,
                                    down_block_additional_residuals=down, mid_block_additional_residual=mid, return_dict=False)[0]
-            if do_cfg:                                                                  # :370-372
-                nu, nt_ = noise_pred.float().chunk(2, dim=0)
-                noise_pred = nu + guidance * (nt_ - nu)
+            if do_cfg:                                                                  # :370-372  eps_u + g (eps_t - eps_u)
+                nu, nt_ = (t_.contiguous() for t_ in noise_pred.float().chunk(2, dim=0))
+                noise_pred = ops.lincomb([(1.0 - guidance, nu), (guidance, nt_)])
             latents = self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]   # :375
             if callback is not None:                                                    # :378-381
                 loc = dict(latents=latents, prompt_embeds=pe, noise_pred=noise_pred)

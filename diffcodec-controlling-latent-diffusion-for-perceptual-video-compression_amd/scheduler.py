@@ -79,3 +79,120 @@ class DDIMScheduler:
         scratch = torch.empty((b, h, w, c), device=dev, dtype=torch.bfloat16)
         ops.cfg_ddim_step(eps, lat, scratch, coef, step, 1.0, False)
         return (lat,) if not return_dict else type("DDIMOut", (), {"prev_sample": lat})()
+
+
+class UniPCMultistepScheduler:
+    """The scheduler the reference actually instantiates (validation.py:37, `UniPCMultistepScheduler.from_pretrained(base,
+    subfolder="scheduler")`): diffusers' UniPC with its defaults on top of the SD-1.5 scheduler_config — solver_order 2,
+    bh2, predict_x0, lower_order_final, epsilon prediction, leading spacing, steps_offset 1, final sigma 0 [recalled; the
+    reference holds no fixture -> parity unpinned].  All coefficients are host scalars; every tensor update is one
+    `dc_lincomb4_f32` launch on fp32 state."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 solver_order=2, prediction_type="epsilon", predict_x0=True, solver_type="bh2", lower_order_final=True,
+                 timestep_spacing="leading", steps_offset=1, final_sigmas_type="zero", **unused):
+        if (beta_schedule, prediction_type, predict_x0, solver_type, timestep_spacing, final_sigmas_type) != \
+                ("scaled_linear", "epsilon", True, "bh2", "leading", "zero") or solver_order not in (1, 2):
+            raise NotImplementedError("only the configuration the reference runs is implemented")
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        self.solver_order, self.lower_order_final = solver_order, lower_order_final
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps, device=None, **kw):
+        n = num_inference_steps
+        ratio = self.num_train_timesteps // (n + 1)
+        ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + self.steps_offset
+        ac = self.alphas_cumprod.double().numpy()
+        sig = ((1 - ac) / ac) ** 0.5
+        sig = np.interp(ts, np.arange(0, len(sig)), sig)
+        self.sigmas = np.concatenate([sig, [0.0]])
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = n
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums, self.last_sample, self.step_index, self.this_order = 0, None, None, 1
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha = 1.0 / (sigma * sigma + 1.0) ** 0.5
+        return alpha, sigma * alpha
+
+    @staticmethod
+    def _lam(alpha, sigma):
+        return np.log(alpha) - (np.log(sigma) if sigma > 0 else -np.inf)
+
+    def _rhos_and_h(self, order, lam_t, lam_s0, lam_prev):
+        """shared coefficient algebra of uni_p / uni_c: returns (h_phi_1, B_h, rks, R, b)."""
+        h = lam_t - lam_s0
+        rks = [(lam_prev[i] - lam_s0) / h for i in range(order - 1)] + [1.0]
+        hh = -h
+        h_phi_1 = np.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1.0 if np.isfinite(hh) else -1.0
+        b_h = np.expm1(hh)
+        rr, bb, fact = [], [], 1.0
+        for i in range(1, order + 1):
+            rr.append([rk ** (i - 1) for rk in rks])
+            bb.append(h_phi_k * fact / b_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1.0 / fact if np.isfinite(hh) else -1.0 / fact
+        return h_phi_1, b_h, rks, np.array(rr, dtype=np.float64), np.array(bb, dtype=np.float64)
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        if self.step_index is None:
+            idx = (self.timesteps == int(timestep)).nonzero()
+            if idx.numel() == 0:
+                raise ValueError(f"timestep {timestep} is not in the current schedule")
+            self.step_index = int(idx[0])
+        i = self.step_index
+        x = sample.float().contiguous()
+        eps = model_output.float().contiguous()
+        if eps.shape != x.shape:
+            raise ValueError("model_output and sample must have the same shape")
+        a_i, s_i = self._alpha_sigma(self.sigmas[i])
+        m_t = ops.lincomb([(1.0 / a_i, x), (-s_i / a_i, eps)])                      # convert_model_output: x0 prediction
+        if i > 0 and self.last_sample is not None:                                # ---- corrector (multistep_uni_c_bh_update)
+            order = self.this_order
+            m0 = self.model_outputs[-1]
+            a_t, s_t = self._alpha_sigma(self.sigmas[i])
+            a_s, s_s = self._alpha_sigma(self.sigmas[i - 1])
+            lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - (k + 1)])) for k in range(1, order)]
+            h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
+            rhos = np.array([0.5]) if order == 1 else np.linalg.solve(rr, bb)
+            terms = {"x": s_t / s_s, "m0": -a_t * h_phi_1, "mt": -a_t * b_h * rhos[-1]}
+            terms["m0"] += a_t * b_h * rhos[-1]                                     # D1_t = m_t - m0
+            m1 = None
+            if order == 2:
+                m1 = self.model_outputs[-2]
+                c1 = -a_t * b_h * rhos[0] / rks[0]                                  # corr_res = rho * (m1 - m0) / rk
+                terms["m0"] -= c1
+                terms["m1"] = c1
+            x = ops.lincomb([(terms["x"], self.last_sample), (terms["m0"], m0), (terms["mt"], m_t), (terms.get("m1", 0.0), m1)])
+        for k in range(self.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = m_t
+        this_order = min(self.solver_order, len(self.timesteps) - i) if self.lower_order_final else self.solver_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = x
+        # ---- predictor (multistep_uni_p_bh_update)
+        order = self.this_order
+        a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
+        a_s, s_s = self._alpha_sigma(self.sigmas[i])
+        lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - k])) for k in range(1, order)]
+        h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
+        c_x, c_m0, c_m1, m1 = s_t / s_s, -a_t * h_phi_1, 0.0, None
+        if order == 2:
+            m1 = self.model_outputs[-2]
+            c = -a_t * b_h * 0.5 / rks[0]                                           # rhos_p = [0.5]; D1 = (m1 - m0) / rk
+            c_m0 -= c
+            c_m1 = c
+        prev = ops.lincomb([(c_x, x), (c_m0, m_t), (c_m1, m1)])
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return (prev,) if not return_dict else type("UniPCOut", (), {"prev_sample": prev})()

@@ -147,6 +147,10 @@ int dc_timestep_embedding_f32(const float* t_dev, const int* step_dev, float* ou
  * 0/1 get their 2x2 lowest-frequency block scaled by s (fourier_filter, threshold 1); the backbone's first C/2 channels get *b. */
 int dc_freeu_lowfreq_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, float s, void* stream);
 int dc_freeu_backbone_nhwc_bf16(const void* x, void* y, long long pixels, int C, float b, void* stream);
+/* y = a*x0 + b*x1 + c*x2 + d*x3 on fp32 tensors (x1..x3 may be NULL): `scheduler.step` of the multistep schedulers the reference
+ * instantiates (UniPCMultistepScheduler, validation.py:37) and the CFG combine of the generic loop (pipeline.py:370-375). */
+int dc_lincomb4_f32(const float* x0, const float* x1, const float* x2, const float* x3, float a, float b, float c, float d,
+                    float* y, long long n, void* stream);
 /* dst[c][r] = src[r][c], bf16, batch of `batch` matrices (VAE attention: V -> V^T). */
 int dc_transpose_bf16(const void* src, void* dst, int batch, int R, int C, void* stream);
 /* DiagonalGaussianDistribution.sample() * scale — train_controlnet.py:1081, pipeline.ipynb cell 7:

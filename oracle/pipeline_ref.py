@@ -39,6 +39,93 @@ class DDIMRef:
         return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
 
 
+class UniPCRef:
+    """diffusers UniPCMultistepScheduler (solver_order 2, bh2, predict_x0, lower_order_final, leading spacing,
+    steps_offset 1, final sigma 0) as instantiated at validation.py:37 [recalled; parity unpinned].  Written in the
+    library's tensor form (D1s / rhos / einsum), independently of the product's folded scalar coefficients."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, T=1000, beta_start=0.00085, beta_end=0.012, solver_order=2):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=torch.float32) ** 2
+        self.ac = torch.cumprod(1.0 - betas, dim=0).double()
+        self.T, self.solver_order = T, solver_order
+
+    def set_timesteps(self, n):
+        ratio = self.T // (n + 1)
+        ts = (np.arange(0, n + 1) * ratio).round()[::-1][:-1].copy().astype(np.int64) + 1
+        sig = (((1 - self.ac) / self.ac) ** 0.5).numpy()
+        self.sigmas = torch.from_numpy(np.concatenate([np.interp(ts, np.arange(0, len(sig)), sig), [0.0]]))
+        self.timesteps = torch.from_numpy(ts)
+        self.model_outputs = [None] * self.solver_order
+        self.lower_order_nums, self.last_sample, self.step_index, self.this_order = 0, None, 0, 1
+
+    @staticmethod
+    def _as(sigma):
+        alpha = 1 / (sigma ** 2 + 1) ** 0.5
+        return alpha, sigma * alpha
+
+    def _update(self, x, m0, older, sig_t, sig_s0, sig_prev, order, model_t=None):
+        a_t, s_t = self._as(sig_t)
+        a_s, s_s = self._as(sig_s0)
+        lam_t, lam_s = torch.log(a_t) - torch.log(s_t), torch.log(a_s) - torch.log(s_s)
+        h = lam_t - lam_s
+        rks, d1s = [], []
+        for k in range(order - 1):
+            a_k, s_k = self._as(sig_prev[k])
+            rk = ((torch.log(a_k) - torch.log(s_k)) - lam_s) / h
+            rks.append(rk)
+            d1s.append((older[k] - m0) / rk)
+        rks.append(torch.tensor(1.0, dtype=torch.float64))
+        rks = torch.stack(rks)
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        b_h = torch.expm1(hh)
+        rr, bb, fact = [], [], 1
+        for i in range(1, order + 1):
+            rr.append(rks ** (i - 1))
+            bb.append(h_phi_k * fact / b_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        rr, bb = torch.stack(rr), torch.stack(bb)
+        x_t_ = s_t / s_s * x - a_t * h_phi_1 * m0
+        if model_t is None:                                   # predictor
+            res = 0.5 * d1s[0] if order == 2 else 0.0
+            return x_t_ - a_t * b_h * res
+        rhos = torch.tensor([0.5], dtype=torch.float64) if order == 1 else torch.linalg.solve(rr, bb)
+        res = rhos[0] * d1s[0] if order == 2 else 0.0
+        return x_t_ - a_t * b_h * (res + rhos[-1] * (model_t - m0))
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, eps, t, x):
+        i = self.step_index
+        x, eps = x.double(), eps.double()
+        a_i, s_i = self._as(self.sigmas[i])
+        m_t = (x - s_i * eps) / a_i
+        if i > 0 and self.last_sample is not None:
+            o = self.this_order
+            x = self._update(self.last_sample, self.model_outputs[-1], [self.model_outputs[-2]] if o == 2 else [], self.sigmas[i],
+                             self.sigmas[i - 1], [self.sigmas[i - 2]] if o == 2 else [], o, model_t=m_t)
+        for k in range(self.solver_order - 1):
+            self.model_outputs[k] = self.model_outputs[k + 1]
+        self.model_outputs[-1] = m_t
+        self.this_order = min(min(self.solver_order, len(self.timesteps) - i), self.lower_order_nums + 1)
+        self.last_sample = x
+        o = self.this_order
+        if i + 1 == len(self.timesteps):                      # final sigma 0: h = inf, update collapses to the x0 prediction
+            prev = m_t
+        else:
+            prev = self._update(x, m_t, [self.model_outputs[-2]] if o == 2 else [], self.sigmas[i + 1], self.sigmas[i],
+                                [self.sigmas[i - 1]] if o == 2 else [], o)
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev.float()
+
+
 @torch.no_grad()
 def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flow_cond, prompt_embeds,
                  negative_prompt_embeds, latents, num_inference_steps=20, guidance_scale=7.5,

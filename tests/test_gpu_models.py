@@ -285,3 +285,47 @@ def test_freeu_matches_fft_restatement(small):
         pipe.disable_freeu()
     assert T.rel_l2(eps, ref) < 4e-2
     assert T.rel_l2(ref_plain, ref) > 3 * T.rel_l2(eps, ref)          # FreeU really changes the output, and we follow it
+
+
+def test_unipc_scheduler_matches_tensor_form_restatement():
+    """§8(f)-3: the scheduler validation.py:37 instantiates.  Product: folded host scalars + dc_lincomb4_f32 launches;
+    oracle: the library's tensor form in float64.  Driven by a random epsilon sequence (scheduler-level test)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    from oracle.pipeline_ref import UniPCRef
+    for n in (4, 20):
+        s, r = UniPCMultistepScheduler(), UniPCRef()
+        s.set_timesteps(n)
+        r.set_timesteps(n)
+        assert torch.equal(s.timesteps, r.timesteps)
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(2, 4, 16, 16, generator=g)
+        xd, xr = x.to(DEV), x.clone()
+        for t in s.timesteps.tolist():
+            eps = torch.randn(2, 4, 16, 16, generator=g)
+            xd = s.step(eps.to(DEV), t, xd, return_dict=False)[0]
+            xr = r.step(eps, t, xr)
+            torch.testing.assert_close(xd.cpu(), xr, rtol=2e-4, atol=2e-4)
+    s.set_timesteps(20)
+    assert s.timesteps[0].item() == 941 and s.timesteps[-1].item() == 48      # leading spacing over N+1 = 21 intervals, offset 1
+
+
+def test_pipeline_with_unipc_and_freeu_like_validation_py(small):
+    """validation.py:37,106,132-146 configuration (UniPC + FreeU) through the generic loop: runs, finite, differs from DDIM."""
+    T, pipe, _ = small
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    cond, flow, pe, npe, lat = _inputs(T)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=4, guidance_scale=3.5, controlnet_conditioning_scale=1.35, output_type="pt")
+    base = pipe(**kw).images.float().cpu()
+    ddim = pipe.scheduler
+    pipe.scheduler = UniPCMultistepScheduler()
+    pipe.enable_freeu(s1=0.9, s2=0.2, b1=1.2, b2=1.4)
+    try:
+        img = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.disable_freeu()
+        pipe.scheduler = ddim
+    assert torch.isfinite(img).all() and img.shape == base.shape and 0.0 <= img.min() and img.max() <= 1.0
+    assert T.psnr(img, base) < 40.0
