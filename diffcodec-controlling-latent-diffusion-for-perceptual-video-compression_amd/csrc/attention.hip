@@ -12,6 +12,7 @@
 // Head dims that are not multiples of 16/32 (d = 40) are zero-padded in LDS/registers.
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -35,7 +36,9 @@ struct AttnArgs {
 
 // launch bound of 2 waves/SIMD (<= 256 registers) for the small heads: hipcc then emits the VGPR form of the MFMA;
 // at 1 wave/SIMD it parks accumulators in AGPRs and pays ~180 v_accvgpr moves per K/V tile in the softmax.
-template <int D>
+// QB = 32-query blocks per wave: with QB = 2 every K fragment and every transposed V read feeds two MFMAs, and the
+// staging / barrier cost per key tile is shared by 256 queries per workgroup instead of 128.
+template <int D, int QB>
 __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
 {
     constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     constexpr int V_PITCH = v_pitch_bytes(NDT);
     constexpr int VT_BYTES = KV_TILE * V_PITCH;
     constexpr int BUF = K_BYTES + VT_BYTES;
+    constexpr int QW = 32 * QB;                      // queries per wave
     static_assert(NDT <= 5, "head dim <= 160");
     // Row sums for free: when the head dim leaves a spare zero-padded column (d = 40, 80, 8, 16), V's column D is set to
     // 1.0 in LDS, so O^T row D accumulates sum_k p — the softmax denominator — inside the PV MFMA, already rescaled by
@@ -59,11 +63,11 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int qblocks = (a.Nq + 127) / 128;
+    const int qblocks = (a.Nq + 4 * QW - 1) / (4 * QW);
     const int bh = blockIdx.x / qblocks;
     const int qb = blockIdx.x - bh * qblocks;
     const int b = bh / a.heads, h = bh - b * a.heads;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * 4 * QW + wave * QW;
 
     const bf16_t* __restrict__ Q = a.q + (long long)b * a.Nq * a.qs + h * D;
     const bf16_t* __restrict__ K = a.k + (long long)b * a.Nk * a.ks + h * D;
@@ -77,22 +81,32 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             *(unsigned short*)(smem + (tid >> 6) * BUF + K_BYTES + (tid & 63) * V_PITCH + D * 2) = 0x3F80;   // bf16 1.0
     }
 
-    // Q^T fragments: lane holds Q[q0+lq][16*ks + 8*lh .. +7]
-    bf16x8 qf[ND16];
+    // Q^T fragments: lane holds Q[q0 + 32*u + lq][16*ks + 8*lh .. +7]
+    bf16x8 qf[QB][ND16];
 #pragma unroll
-    for (int ks = 0; ks < ND16; ++ks) {
-        const int dcol = 16 * ks + 8 * lh;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (q0 + lq < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)(q0 + lq) * a.qs + dcol);
-        qf[ks] = *(bf16x8*)&v;
-    }
+    for (int u = 0; u < QB; ++u)
+#pragma unroll
+        for (int ks = 0; ks < ND16; ++ks) {
+            const int dcol = 16 * ks + 8 * lh;
+            const int qi = q0 + 32 * u + lq;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (qi < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)qi * a.qs + dcol);
+            qf[u][ks] = *(bf16x8*)&v;
+        }
 
-    f32x16 oacc[NDT];
+    f32x16 oacc[QB][NDT];
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
+    for (int u = 0; u < QB; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[u][t][r] = 0.f;
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) {
+        m_run[u] = -INFINITY;
+        l_run[u] = 0.f;
+    }
 
     u32x4 rk[NLD], rv[NLD];
     const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
@@ -126,79 +140,87 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         }
     };
 
-    __syncthreads();                  // zero-fill complete before the first tile lands
+    __syncthreads();                  // zero-fill (and the ones column) complete before the first tile lands
     issue_loads(0);
     store_lds(0);
     __syncthreads();
 
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < ntiles;
         if (more) issue_loads(t + 1);
         const char* sK = smem + buf * BUF;
         const char* sV = sK + K_BYTES;
-
-        // ---- S^T tiles (2 x 32 keys)
-        f32x16 s[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < ND16; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(sK + (32 * j + lq) * K_PITCH + (16 * ks + 8 * lh) * 2);
-                s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
-            }
-        }
-        // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
-        //      are one FMA feeding v_exp_f32 directly; key masking only exists in the (wave-uniform) ragged last tile.
         const int kb = t * KV_TILE;
-        if (kb + KV_TILE > a.Nk) {
+
+        // ---- S^T tiles (2 x 32 keys) for every query block: each K fragment feeds QB MFMAs
+        f32x16 s[QB][2];
+#pragma unroll
+        for (int u = 0; u < QB; ++u)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key >= a.Nk) s[j][r] = -INFINITY;
-                }
-        }
-        float mloc = s[0][0];
+                for (int r = 0; r < 16; ++r) s[u][j][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[j][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float mc = m_new * a.scale_log2e;
-        float lsum = 0.f;
-        bf16x8 pf[2][2];
-        typedef __attribute__((ext_vector_type(2))) float f32x2;
-        const f32x2 c2 = {a.scale_log2e, a.scale_log2e}, mc2 = {mc, mc};
+            for (int ks = 0; ks < ND16; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (32 * j + lq) * K_PITCH + (16 * ks + 8 * lh) * 2);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 sv = {s[j][r], s[j][r + 1]};
-                const f32x2 t = sv * c2 - mc2;                   // v_pk_fma_f32
-                const float p0 = __builtin_amdgcn_exp2f(t[0]), p1 = __builtin_amdgcn_exp2f(t[1]);
-                if (!ONES) lsum += p0 + p1;
-                pf[j][r >> 3][r & 7] = (bf16_t)p0;
-                pf[j][r >> 3][(r & 7) + 1] = (bf16_t)p1;
+                for (int u = 0; u < QB; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][j], 0, 0, 0);
             }
-        if (__any(m_new != m_run)) {                     // the max moved for some query of this wave: rescale O and l
-            const float alpha = __builtin_amdgcn_exp2f(m_run * a.scale_log2e - mc);   // 0 on the first tile (m_run = -inf)
-            if (!ONES) l_run *= alpha;
+
+        // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
+        //      are one (packed) FMA feeding v_exp_f32 directly; key masking only exists in the ragged last tile.
+        bf16x8 pf[QB][2][2];
 #pragma unroll
-            for (int tt = 0; tt < NDT; ++tt)
+        for (int u = 0; u < QB; ++u) {
+            if (kb + KV_TILE > a.Nk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[tt][r] *= alpha;
-            m_run = m_new;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key >= a.Nk) s[u][j][r] = -INFINITY;
+                    }
+            }
+            float mloc = s[u][0][0];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[u][j][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[u], mloc);
+            const float mc = m_new * a.scale_log2e;
+            float lsum = 0.f;
+            const f32x2 c2 = {a.scale_log2e, a.scale_log2e}, mc2 = {mc, mc};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 sv = {s[u][j][r], s[u][j][r + 1]};
+                    const f32x2 tt2 = sv * c2 - mc2;                 // v_pk_fma_f32
+                    const float p0 = __builtin_amdgcn_exp2f(tt2[0]), p1 = __builtin_amdgcn_exp2f(tt2[1]);
+                    if (!ONES) lsum += p0 + p1;
+                    pf[u][j][r >> 3][r & 7] = (bf16_t)p0;
+                    pf[u][j][r >> 3][(r & 7) + 1] = (bf16_t)p1;
+                }
+            if (__any(m_new != m_run[u])) {                  // the max moved for some query of this block: rescale O and l
+                const float alpha = __builtin_amdgcn_exp2f(m_run[u] * a.scale_log2e - mc);   // 0 on the first tile
+                if (!ONES) l_run[u] *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[u][tt][r] *= alpha;
+                m_run[u] = m_new;
+            }
+            if (!ONES) l_run[u] += lsum;
         }
-        if (!ONES) l_run += lsum;
 
         // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
         // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
-        // and receives d = block + j16 for the block's 4 keys.
+        // and receives d = block + j16 for the block's 4 keys; each V fragment feeds QB MFMAs.
         const char* vbase = sV + (4 * lh + ((lane & 15) >> 2)) * V_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int tt = 0; tt < NDT; ++tt) {
@@ -211,7 +233,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pk + 8 * V_PITCH));
                     u32x2 l2 = *(const u32x2*)&lo, h2 = *(const u32x2*)&hi;
                     u32x4 av = {l2[0], l2[1], h2[0], h2[1]};
-                    oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[j][s2], oacc[tt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < QB; ++u)
+                        oacc[u][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[u][j][s2], oacc[u][tt], 0, 0, 0);
                 }
         }
         if (more) store_lds(buf ^ 1);
@@ -219,44 +243,59 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
 
     // ---- finish: O[q][d] = O^T[d][q] / l
-    float l_tot;
-    if (ONES) l_tot = __shfl(oacc[ONES_T][ONES_R], lq, 64);          // row D of O^T lives in the lower lane half
-    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + lq;
-    if (qi < a.Nq) {
-        bf16_t* __restrict__ O = a.o + ((long long)b * a.Nq + qi) * a.os + h * D;
 #pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
+    for (int u = 0; u < QB; ++u) {
+        float l_tot;
+        if (ONES) l_tot = __shfl(oacc[u][ONES_T][ONES_R], lq, 64);          // row D of O^T lives in the lower lane half
+        else l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + 32 * u + lq;
+        if (qi < a.Nq) {
+            bf16_t* __restrict__ O = a.o + ((long long)b * a.Nq + qi) * a.os + h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dcol = 32 * tt + 8 * g + 4 * lh;
-                if (dcol < D) {
-                    bf16x4 pk;
+            for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(oacc[tt][4 * g + r] * inv);
-                    *(bf16x4*)(O + dcol) = pk;
+                for (int g = 0; g < 4; ++g) {
+                    const int dcol = 32 * tt + 8 * g + 4 * lh;
+                    if (dcol < D) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(oacc[u][tt][4 * g + r] * inv);
+                        *(bf16x4*)(O + dcol) = pk;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int D>
-int launch(const AttnArgs& a, hipStream_t st)
+template <int D, int QB>
+int launch_qb(const AttnArgs& a, hipStream_t st)
 {
     constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
     constexpr int KP16 = (ND16 * 2) | 1;
     constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
     const size_t lds = 2 * BUF;
-    auto kern = attn_kernel<D>;
+    auto kern = attn_kernel<D, QB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int qblocks = (a.Nq + 127) / 128;
+    const int qblocks = (a.Nq + 128 * QB - 1) / (128 * QB);
     hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);
     return dc_launch_status();
+}
+
+template <int D>
+int launch(const AttnArgs& a, hipStream_t st)
+{
+    // two query blocks per wave only for the small heads (register budget) and only when that still leaves >= 2 workgroups per CU
+    static const int force_qb = getenv("DC_ATTN_QB") ? atoi(getenv("DC_ATTN_QB")) : 0;      // developer knob
+    if constexpr (D <= 80) {
+        const long long wgs2 = (long long)a.B * a.heads * ((a.Nq + 255) / 256);
+        if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) return launch_qb<D, 2>(a, st);
+    }
+    return launch_qb<D, 1>(a, st);
 }
 
 // Row softmax fp32 -> bf16 (one workgroup per row; cols <= 65536).
