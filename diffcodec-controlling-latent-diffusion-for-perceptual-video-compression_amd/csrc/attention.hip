@@ -291,7 +291,7 @@ int launch(const AttnArgs& a, hipStream_t st)
 {
     // two query blocks per wave only for the small heads (register budget) and only when that still leaves >= 2 workgroups per CU
     static const int force_qb = getenv("DC_ATTN_QB") ? atoi(getenv("DC_ATTN_QB")) : 0;      // developer knob
-    if constexpr (D <= 80) {
+    if constexpr (D <= 48) {          // d = 80 spills at two blocks per wave (measured slower)
         const long long wgs2 = (long long)a.B * a.heads * ((a.Nq + 255) / 256);
         if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) return launch_qb<D, 2>(a, st);
     }
