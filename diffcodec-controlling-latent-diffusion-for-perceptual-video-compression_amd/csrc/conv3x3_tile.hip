@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * TM;                       // output rows per tile (tile is TH x 16 pixels)
     constexpr int BN = WN * TN * 16;
-    constexpr int HALO_MAX = (TH + 2) * 18;
+    constexpr int HALO_MAX = TM == 4 ? 200 : (TH + 2) * 18;   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
     constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
     constexpr int H_BYTES = HALO_MAX * 128;
@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     // narrow maps (Wo == 8): the 16 lanes of an MFMA row cover 2 image rows of 8 pixels (sh = 1)
     const int sh = d.Wo < 16 ? 1 : 0;
     const int TW = 16 >> sh;
-    const int tiles_x = d.Wo / TW, tiles_y = d.Ho / (TH << sh);
+    // dual: 8x8 maps with the 8-row tile shape — one tile = TWO whole images (wave row wm = image), so the weight tile
+    // streamed per K-step serves 128 pixels instead of 64 at the weight-bound 8x8 layers
+    const bool dual = sh && TM == 4;
+    const int tiles_x = dual ? 1 : d.Wo / TW, tiles_y = dual ? 1 : d.Ho / (TH << sh);
     const int n_tiles = (d.Cout + BN - 1) / BN;
-    const int m_tiles = d.N * tiles_y * tiles_x;
+    const int m_tiles = dual ? d.N / 2 : d.N * tiles_y * tiles_x;
     const int nblk = n_tiles * m_tiles;
     int bid = blockIdx.x;
     {   // XCD-aware remap: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous tile range
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
     const int tile_n = bid % n_tiles;
     int tile_m = bid / n_tiles;
-    const int n_img = tile_m / (tiles_y * tiles_x);
-    tile_m -= n_img * tiles_y * tiles_x;
+    const int n_img0 = dual ? 2 * tile_m : tile_m / (tiles_y * tiles_x);
+    tile_m = dual ? 0 : tile_m - n_img0 * tiles_y * tiles_x;
+    const int n_img = dual ? n_img0 + wm : n_img0;              // image of this wave's output rows
     const int oy0 = (tile_m / tiles_x) * (TH << sh), ox0 = (tile_m % tiles_x) * TW;
     const int fdx = fr & (TW - 1), fdy = fr >> (4 - sh);
     const int n0 = tile_n * BN;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     // ---- halo geometry (input coordinates).  upsample: output tile lives on the 2x grid, halo on the input grid
     const int up = d.upsample;
     const int HWd = up ? 10 : TW + 2;
-    const int HHt = up ? TH / 2 + 2 : (TH << sh) + 2;
+    const int HHt = up ? TH / 2 + 2 : (dual ? 10 : (TH << sh) + 2);
+    const int himg = HHt * HWd;                                 // halo pixels per image (dual: two images back to back)
     const int iy0 = up ? (oy0 >> 1) - 1 : oy0 - 1;
     const int ix0 = up ? (ox0 >> 1) - 1 : ox0 - 1;
     int h_pix[NHU];                                   // input pixel index of each staged unit, -1 = zero padding, -2 = unused
@@ -95,10 +100,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         const int u = tid + 256 * i;
         const int hp = u >> 3;
         int pix = -2;
-        if (hp < HHt * HWd) {
-            const int hy = hp / HWd, hx = hp - hy * HWd;
+        if (hp < (dual ? 2 : 1) * himg) {
+            const int im = hp >= himg ? 1 : 0;
+            const int hq = hp - im * himg;
+            const int hy = hq / HWd, hx = hq - hy * HWd;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            pix = (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) ? (n_img * d.H + iy) * d.W + ix : -1;
+            pix = (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) ? ((n_img0 + im) * d.H + iy) * d.W + ix : -1;
         }
         h_pix[i] = pix;
         h_lds[i] = hp * 128 + ((q ^ (hp & 7)) << 4);
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     const bf16_t* __restrict__ x1 = (const bf16_t*)d.x1;
     const bf16_t* __restrict__ x2 = (const bf16_t*)d.x2;
     const bf16_t* __restrict__ wgt = (const bf16_t*)d.w;
-    const int gn_row = GN ? (n_img % d.gn_batch) : 0;
+    const int gn_row = GN ? (n_img0 % d.gn_batch) : 0;          // (dual tiles are never launched with a fused GN)
 
     u32x4 rh[NHU];
     auto issue_halo = [&](int cc) {
@@ -185,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         for (int tm = 0; tm < TM; ++tm) {
             const int ty = wm * TM + tm;
             prow[tm] = up ? (((ty + ky - 1) >> 1) + 1) * 10 + ((fr + kx - 1) >> 1) + 1
-                          : ((ty << sh) + fdy + ky) * HWd + fdx + kx;
+                          : (dual ? wm * himg + ((tm << 1) + fdy + ky) * HWd + fdx + kx
+                                  : ((ty << sh) + fdy + ky) * HWd + fdx + kx);
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     long long mrow[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int oy = oy0 + ((wm * TM + tm) << sh) + fdy, ox = ox0 + fdx;
+        const int oy = dual ? (tm << 1) + fdy : oy0 + ((wm * TM + tm) << sh) + fdy, ox = ox0 + fdx;
         mrow[tm] = ((long long)n_img * d.Ho + oy) * d.Wo + ox;
     }
     bf16x4 rr[TM][TN];
@@ -300,9 +308,11 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
     const int sh = d.Wo < 16 ? 1 : 0;
-    const int nblk = d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh)) * dc_cdiv(d.Cout, BN);
+    const bool dual = sh && TM == 4;
+    const int nblk = (dual ? d.N / 2 : d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh))) * dc_cdiv(d.Cout, BN);
+    constexpr int HALO_ROWS = TM == 4 ? 200 : (TH + 2) * 18;
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
-    const size_t lds = (TH + 2) * 18 * 128 + NSTB * BN * 128;
+    const size_t lds = HALO_ROWS * 128 + NSTB * BN * 128;
 #define DC_TILE_LAUNCH(GN)                                                                                      \
     do {                                                                                                        \
         auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB>;                                                          \
@@ -337,5 +347,9 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     const long long big = (long long)d.N * (d.Ho / 8) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
     // LDS budget keeps two workgroups per CU: 8-row tile with BN=160 affords a 2-stage weight ring, the others 3 stages
     if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
+    // 8x8 maps: two images per tile when the batch is even, nothing is fused on load and enough tiles remain
+    if (d.Wo == 8 && d.Ho == 8 && (d.N & 1) == 0 && !d.gn_ab &&
+        (long long)(d.N / 2) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1) >= 128)
+        return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }
