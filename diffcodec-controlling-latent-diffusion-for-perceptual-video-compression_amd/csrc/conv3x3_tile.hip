@@ -349,7 +349,7 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     // 8x8 maps: two images per tile when the batch is even, nothing is fused on load and enough tiles remain
     if (d.Wo == 8 && d.Ho == 8 && (d.N & 1) == 0 && !d.gn_ab &&
-        (long long)(d.N / 2) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1) >= 128)
+        (long long)(d.N / 2) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1) >= 512)   // measured: below 2 workgroups/CU the 4-row tiles win
         return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }
