@@ -313,3 +313,16 @@ def test_layout_and_timestep_embedding(ops):
     ref = timestep_embedding(t.expand(3), 320)
     out = ops.timestep_embedding(t.to(DEV), 3, 320).cpu()
     close(out, ref, rtol=1e-4, atol=2e-4)
+
+
+def test_conv_tile_two_images_per_tile(ops):
+    """8x8 maps, even batch, enough tiles: the 8-row tile shape carries two whole images (wave row = image)."""
+    g = torch.Generator().manual_seed(15)
+    n, cin, cout = 8, 640, 1280
+    x = bf(torch.randn(n, cin, 8, 8, generator=g))
+    wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.1
+    temb = torch.randn(n, cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1) + temb[:, :, None, None]
+    out = ops.conv(nhwc(x), ops.PackedConv(wt, b, DEV), row_add=temb.to(DEV), splitk=16)     # (8/2) * 8 N-tiles * 16 = 512 workgroups
+    close(from_nhwc(out), ref)
