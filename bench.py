@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--dual-stream", type=int, default=0, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
     args = ap.parse_args()
@@ -119,6 +120,7 @@ def main():
         torch.cuda.synchronize()
         log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s")
     pipe.enable_hip_graphs(not args.no_graphs)
+    pipe.enable_dual_stream(bool(args.dual_stream))
 
     F = args.frames
     # two alternating input sets (distinct tensors) so that no per-call cache can carry work across steps

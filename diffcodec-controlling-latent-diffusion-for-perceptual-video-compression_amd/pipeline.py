@@ -65,6 +65,7 @@ class StableDiffusionDualFlowControlNetPipeline:
         self._interrupt = False
         self._progress = True
         self._use_graphs = False
+        self._dual_stream = False
         self._graphs = {}
         self._state = {}
         self.device = getattr(unet, "device", torch.device("cuda"))
@@ -92,6 +93,11 @@ class StableDiffusionDualFlowControlNetPipeline:
 
     def enable_hip_graphs(self, flag=True):
         self._use_graphs = bool(flag)
+
+    def enable_dual_stream(self, flag=True):
+        """Run the ControlNet and the UNet down path of each step concurrently on two HIP streams (fused loop only)."""
+        self._dual_stream = bool(flag)
+        self._graphs.clear()
 
     @property
     def interrupt(self):
@@ -307,8 +313,23 @@ class StableDiffusionDualFlowControlNetPipeline:
         ops.latents_to_model_input(st["lat"], 1.0, 2 if do_cfg else 1, out=st["x_in"])
 
         def one_step(scale):
-            down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"])
-            eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"])
+            if not self._dual_stream:
+                down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"])
+                eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"])
+            else:
+                # The ControlNet and the UNet's down path are independent until the skip additions (flownet.py:83-124 vs
+                # pipeline.py:358-367): two HIP streams, joined before the UNet mid block.  Every tensor crossing streams
+                # is either persistent or produced before the join; the side stream re-synchronises at each step start.
+                main = torch.cuda.current_stream()
+                side = st.setdefault("side_stream", torch.cuda.Stream(device=device))
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"])
+                sample, res, temb = unet.encode_nhwc(st["x_in"], ttab, step_dev=st["step"])
+                main.wait_stream(side)
+                for t_ in down + [mid]:
+                    t_.record_stream(main)
+                eps = unet.decode_nhwc(sample, list(res), temb, down, mid)
             ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
 
         for i in range(len(sched.timesteps)):

@@ -87,13 +87,17 @@ class HipUNet2DConditionModel:
         self._ctx_key = key
         self._ctx_keepalive = ctx
 
-    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None):
-        """x NHWC bf16 [n,h,w,4]; t_dev fp32 device scalar (or table indexed by step_dev); residuals NHWC bf16.
-        Returns eps NHWC fp32 [n,h,w,4]."""
+    def encode_nhwc(self, x, t_dev, step_dev=None):
+        """First half (time embedding, conv_in, down blocks): independent of the ControlNet, so the fused pipeline can run
+        it on one stream while the ControlNet runs on another.  Returns (sample, skips, temb)."""
         enc = self.enc
         temb = enc.temb(t_dev, x.shape[0], step_dev)
         sample = ops.conv(x, enc.conv_in)
         sample, res = enc.run_down(sample, temb)
+        return sample, res, temb
+
+    def decode_nhwc(self, sample, res, temb, down_res=None, mid_res=None):
+        enc = self.enc
         if down_res is not None:
             assert len(down_res) == len(res)
             res = [ops.add_bf16(a, b) for a, b in zip(res, down_res)]          # pipeline.py:364 residual injection
@@ -113,6 +117,12 @@ class HipUNet2DConditionModel:
                 sample = ops.conv(sample, blk["up"], upsample=True)            # nearest-2x fused into the conv load
         ab = ops.group_norm_ab(sample, self.norm_out[0], self.norm_out[1], self.cfg["groups"], 1e-5)
         return ops.conv(sample, self.conv_out, gn_ab=ab, gn_silu=True, out_f32=True)
+
+    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None):
+        """x NHWC bf16 [n,h,w,4]; t_dev fp32 device scalar (or table indexed by step_dev); residuals NHWC bf16.
+        Returns eps NHWC fp32 [n,h,w,4]."""
+        sample, res, temb = self.encode_nhwc(x, t_dev, step_dev)
+        return self.decode_nhwc(sample, list(res), temb, down_res, mid_res)
 
     def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict=False, **kw):

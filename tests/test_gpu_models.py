@@ -329,3 +329,22 @@ def test_pipeline_with_unipc_and_freeu_like_validation_py(small):
         pipe.scheduler = ddim
     assert torch.isfinite(img).all() and img.shape == base.shape and 0.0 <= img.min() and img.max() <= 1.0
     assert T.psnr(img, base) < 40.0
+
+
+def test_dual_stream_step_equals_single_stream(small):
+    T, pipe, _ = small
+    cond, flow, pe, npe, lat = _inputs(T)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=3, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+    base = pipe(**kw).images.float().cpu()
+    pipe.enable_dual_stream(True)
+    try:
+        a = pipe(**kw).images.float().cpu()
+        pipe.enable_hip_graphs(True)
+        b = pipe(**kw).images.float().cpu()
+        c = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.enable_hip_graphs(False)
+        pipe.enable_dual_stream(False)
+    for x in (a, b, c):
+        assert T.psnr(x, base) > 36.0
