@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--dual-stream", type=int, default=0, help="1: ControlNet and UNet down path on two HIP streams")
+    ap.add_argument("--dual-stream", type=int, default=1, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
     args = ap.parse_args()

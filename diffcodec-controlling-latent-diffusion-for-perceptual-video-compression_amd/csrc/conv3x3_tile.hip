@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
     wait_vmcnt<0>();
 
+    const long long slab = (long long)d.N * d.Ho * d.Wo * d.Cout;   // elements per split-K slab
     // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3].  Bias / time-embedding row / residual are all
     //      fetched before the arithmetic so the loads overlap instead of forming a chain of dependent L2 round trips.
     f32x4 bv[TN];
@@ -276,9 +277,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             if (nb >= d.Cout) continue;
             f32x4 v = acc[tn][tm];
             const long long off = mrow[tm] * d.Cout + nb;
-            if (d.splitk > 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(d.splitk_ws + off + r, v[r]);
+            if (d.splitk > 1) {                                   // this split's own fp32 slab: plain stores, no atomics
+                *(f32x4*)(d.splitk_ws + (long long)blockIdx.y * slab + off) = v;
                 continue;
             }
             v += bv[tn];

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     }
     DC_STAMP_AT(2);
 
+    const long long slab = (long long)d.N * d.Ho * d.Wo * d.Cout;   // elements per split-K slab
     // ---- epilogue.  bf16 outputs go through LDS so that global stores (and residual loads) are whole 16-byte pieces of
     //      contiguous output rows: the MFMA layout gives each lane 4 channels of one pixel, i.e. 32-byte row fragments
     //      per store instruction; staged, every row leaves as BN*2 contiguous bytes.
@@ -335,9 +336,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             if (nb >= d.Cout) continue;
             f32x4 v = acc[tn][tm];
             const long long off = (long long)m * d.Cout + nb;
-            if (d.splitk > 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(d.splitk_ws + off + r, v[r]);
+            if (d.splitk > 1) {                                   // this split's own fp32 slab: plain stores, no atomics
+                *(f32x4*)(d.splitk_ws + (long long)blockIdx.y * slab + off) = v;
                 continue;
             }
             if (d.bias) v += *(const f32x4*)(d.bias + nb);

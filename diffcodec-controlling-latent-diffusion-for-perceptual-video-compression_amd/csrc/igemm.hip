@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
         buf ^= 1;
     }
 
+    const long long slab = (long long)d.N * d.Ho * d.Wo * d.Cout;   // elements per split-K slab
     // ---- epilogue: lane holds out[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
     const int fr = lane & 15;
     const int fq = lane >> 4;
@@ -269,9 +270,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
             if (nb >= d.Cout) continue;
             f32x4 v = acc[tn][tm];
             const long long off = (long long)m * d.Cout + nb;
-            if (d.splitk > 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(d.splitk_ws + off + r, v[r]);
+            if (d.splitk > 1) {                                   // this split's own fp32 slab: plain stores, no atomics
+                *(f32x4*)(d.splitk_ws + (long long)blockIdx.y * slab + off) = v;
                 continue;
             }
             if (d.bias) v += *(const f32x4*)(d.bias + nb);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
     }
 }
 
-// Second pass of split-K: workspace -> bias / row_add / scale / residual -> output.
+// Second pass of split-K: sum of the per-split slabs -> bias / row_add / scale / residual -> output.
 __global__ void splitk_finish_kernel(const dc_conv_desc d, long long total4)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,6 +308,7 @@ __global__ void splitk_finish_kernel(const dc_conv_desc d, long long total4)
     const long long m = off / d.Cout;
     const int nimg = (int)(m / (d.Ho * d.Wo));
     f32x4 v = *(const f32x4*)(d.splitk_ws + off);
+    for (int k = 1; k < d.splitk; ++k) v += *(const f32x4*)(d.splitk_ws + k * total4 * 4 + off);   // fixed order: deterministic
     if (d.bias) v += *(const f32x4*)(d.bias + nb);
     if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
     if (d.act == 1) {
@@ -365,7 +366,7 @@ int launch_cfg(const dc_conv_desc& d, hipStream_t st)
 extern "C" long long dc_conv_igemm_ws_bytes(const dc_conv_desc* d)
 {
     if (!d || d->splitk <= 1) return 0;
-    return (long long)d->N * d->Ho * d->Wo * d->Cout * 4;
+    return (long long)d->N * d->Ho * d->Wo * d->Cout * 4 * d->splitk;
 }
 
 extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
@@ -393,7 +394,16 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     if (d.epilogue == 1 && (d.splitk > 1 || (d.Cout & 31) || d.residual || d.row_add || d.out_f32)) return DC_ERR_INVALID;
     if (d.splitk > 1) {
         if (!d.splitk_ws) return DC_ERR_INVALID;
-        if (hipMemsetAsync(d.splitk_ws, 0, (size_t)dc_conv_igemm_ws_bytes(&d), st) != hipSuccess) return DC_ERR_LAUNCH;
+        // every split must own a non-empty K range, or its slab would stay unwritten: shrink to the fixpoint of
+        // splitk = ceil(KT / ceil(KT / splitk)) (KT = 64-wide K steps, the unit all three kernels partition by)
+        const int nkc = (d.C1 + d.C2) >> 6;
+        const bool tile = !dc_gemm_dma_supported(d) && dc_conv3x3_tile_supported(d);     // splits channel chunks, not taps
+        const int KT = (d.ksize == 3 && !tile) ? 9 * nkc : nkc;
+        for (;;) {
+            const int per = (KT + d.splitk - 1) / d.splitk, s2 = (KT + per - 1) / per;
+            if (s2 == d.splitk) break;
+            d.splitk = s2;
+        }
     }
     const long long M = (long long)d.N * d.Ho * d.Wo;
     // Tile choice: wide-N tile (160) when Cout is a multiple of 160 (all SD-1.5 UNet widths), else 128;

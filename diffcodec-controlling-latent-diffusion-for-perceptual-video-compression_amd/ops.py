@@ -80,15 +80,23 @@ class PackedConvF32:
 
 
 # ------------------------------------------------------------------------------------------ conv / linear
-def _pick_splitk(m, cout, kt):
-    """Split the K loop over workgroups when the output has too few tiles to fill 256 CUs x 2 workgroups and K is long
-    (weight-streaming layers at 8x8 / 16x16).  Partials meet by fp32 atomics in a workspace (1.3 TB/s atomic rate:
-    m*cout*4*splitk bytes must stay small next to the weight stream)."""
+def _pick_splitk(m, cout, kt, units=None):
+    """Split the K loop over workgroups when the output has too few tiles to fill 256 CUs and K is long (the
+    weight-streaming layers at 8x8 / 16x16).  Each split stores its partial tile into its own fp32 slab and a finish
+    pass sums the slabs (m*cout*4 bytes written and read once per split: cheap next to the weight stream, and
+    deterministic).  `units` = what the launched kernel partitions (64-channel chunks for the halo-tile 3x3 kernel,
+    64-wide K steps otherwise); an even partition is preferred, so the split is a divisor of `units`."""
+    units = kt if units is None else units
     bn = 160 if cout % 160 == 0 else 128
     tiles = math.ceil(m / 64) * math.ceil(cout / bn)
-    if tiles >= 384 or kt < 64:
+    if tiles >= 512 or kt < 64:
         return 1
-    return int(max(1, min(16, kt // 8, math.ceil(512 / tiles))))
+    divs = [s for s in range(1, min(units, 20) + 1) if units % s == 0 and kt // s >= 8]
+    target = 1024 if m >= 2048 else 256      # measured (tools/bench_splitk.py): ~1 workgroup per CU at small m, 2+ above
+    for s in divs:
+        if tiles * s >= target:
+            return s
+    return divs[-1] if divs else 1
 
 
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
@@ -129,8 +137,9 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     m = n * ho * wo
     kt = (9 if k == 3 else 1) * (pc.cin // 64)
     if splitk is None:
-        splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt)
-    ws = torch.empty((m, pc.cout), device=x1.device, dtype=F32) if splitk > 1 else None
+        tile3 = k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample)
+        splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else kt)
+    ws = torch.empty((splitk, m, pc.cout), device=x1.device, dtype=F32) if splitk > 1 else None
     if gn_ab is not None:
         _chk(gn_ab, F32, "gn_ab")
         assert gn_ab.shape[1] == pc.cin

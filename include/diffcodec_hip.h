@@ -79,7 +79,7 @@ typedef struct dc_conv_desc {
     const float* row_add;   /* [N][Cout] fp32 added per sample (time-embedding projection) or NULL */
     const void* residual;   /* NHWC bf16 [M][Cout] added after scaling, or NULL */
     void* out;              /* bf16 [M][Cout] (f32 if out_f32; [M][Cout/2] for GEGLU) */
-    float* splitk_ws;       /* fp32 [M][Cout] when splitk > 1 (zeroed by the launcher) */
+    float* splitk_ws;       /* fp32 [splitk][M][Cout] when splitk > 1: one slab per split, summed by the finish pass */
     int N, H, W;            /* input dims (before the fused upsample) */
     int C1, C2, Cout;
     int ksize;              /* 1 or 3 */
