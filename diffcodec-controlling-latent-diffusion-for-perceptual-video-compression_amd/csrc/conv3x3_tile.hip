@@ -282,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 continue;
             }
             v += bv[tn];
-            if (d.act == 1) {
+            if (d.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
             }
             v *= d.out_scale;
             if (d.residual) {

@@ -22,6 +22,8 @@ __device__ __forceinline__ float dc_bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t dc_f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 
 __device__ __forceinline__ float dc_silu(float x) { return x / (1.0f + __expf(-x)); }
+// dc_conv_desc.act: 1 = SiLU, 2 = quick-GELU x * sigmoid(1.702 x) (CLIP text MLP)
+__device__ __forceinline__ float dc_act(float x, int act) { return x / (1.0f + __expf(act == 2 ? -1.702f * x : -x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output rounding): 1 rcp + 1 exp + 7 fma
 // instead of libm erff's branchy polynomial (~3x the VALU work in the GEGLU epilogue).
 __device__ __forceinline__ float dc_erf_fast(float x)

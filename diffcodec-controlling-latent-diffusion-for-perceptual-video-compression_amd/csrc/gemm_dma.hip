@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                     const int nb = n0 + nl;
                     f32x4 v = acc[tn][tm] + bv[tn];
                     if (d.row_add && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-                    if (d.act == 1) {
+                    if (d.act) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+                        for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
                     }
                     if (d.out_scale != 1.0f) v *= d.out_scale;
                     if (d.residual) {
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             }
             if (d.bias) v += *(const f32x4*)(d.bias + nb);
             if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-            if (d.act == 1) {
+            if (d.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
             }
             v *= d.out_scale;
             if (d.residual) {

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
             }
             if (d.bias) v += *(const f32x4*)(d.bias + nb);
             if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-            if (d.act == 1) {
+            if (d.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
             }
             v *= d.out_scale;
             if (d.residual) {
@@ -311,9 +311,9 @@ __global__ void splitk_finish_kernel(const dc_conv_desc d, long long total4)
     for (int k = 1; k < d.splitk; ++k) v += *(const f32x4*)(d.splitk_ws + k * total4 * 4 + off);   // fixed order: deterministic
     if (d.bias) v += *(const f32x4*)(d.bias + nb);
     if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-    if (d.act == 1) {
+    if (d.act) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = dc_silu(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
     }
     v *= d.out_scale;
     if (d.residual) {
@@ -389,6 +389,7 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
         if (ho != d.Ho || wo != d.Wo) return DC_ERR_INVALID;
     }
     if (d.gn_ab && d.gn_batch <= 0) return DC_ERR_INVALID;
+    if (d.act < 0 || d.act > 2) return DC_ERR_INVALID;
     if (d.splitk < 1) d.splitk = 1;
     if (d.row_add_stride == 0) d.row_add_stride = d.Cout;
     if (d.epilogue == 1 && (d.splitk > 1 || (d.Cout & 31) || d.residual || d.row_add || d.out_f32)) return DC_ERR_INVALID;

@@ -48,6 +48,8 @@ SIGNATURES = {
     "dc_fdn_modulate_nhwc_bf16": [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     "dc_layernorm_bf16": [vp, vp, vp, vp, i64, i32, f32, vp],
     "dc_attention_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp],
+    "dc_attention_causal_small_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp],
+    "dc_embed_tokens_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "dc_softmax_rows_f32_to_bf16": [vp, vp, i64, i32, f32, vp],
     "dc_timestep_embedding_f32": [vp, vp, vp, i32, i32, vp],
     "dc_freeu_lowfreq_nhwc_bf16": [vp, vp, i32, i32, i32, i32, f32, vp],

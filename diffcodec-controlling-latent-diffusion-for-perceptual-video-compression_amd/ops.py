@@ -277,6 +277,31 @@ def attention(q, k, v, heads, scale=None):
     return out
 
 
+def attention_causal(q, k, v, heads, scale=None):
+    """Causal self-attention over a short context (CLIP text, T <= 128): same operand convention as `attention`."""
+    b, t, c = q.shape
+    d = c // heads
+    for x in (q, k, v):
+        assert x.dtype == BF16 and x.is_cuda and x.stride(2) == 1 and x.stride(0) == x.shape[1] * x.stride(1) and x.shape[1] == t
+    out = torch.empty((b, t, c), device=q.device, dtype=BF16)
+    lib.call("dc_attention_causal_small_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), b, heads, t, d,
+             q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale if scale is not None else d ** -0.5), _stream())
+    return out
+
+
+def embed_tokens(ids, tok_emb, pos_emb):
+    """ids int64 [B,T] -> bf16 [B,T,C] = tok_emb[ids] + pos_emb[:T]."""
+    assert ids.dtype == torch.int64 and ids.is_cuda and ids.is_contiguous() and ids.dim() == 2
+    _chk(tok_emb, BF16, "tok_emb")
+    _chk(pos_emb, BF16, "pos_emb")
+    b, t = ids.shape
+    assert t <= pos_emb.shape[0]
+    out = torch.empty((b, t, tok_emb.shape[1]), device=ids.device, dtype=BF16)
+    lib.call("dc_embed_tokens_bf16", ids.data_ptr(), tok_emb.data_ptr(), pos_emb.data_ptr(), out.data_ptr(), b, t,
+             tok_emb.shape[1], tok_emb.shape[0], _stream())
+    return out
+
+
 def softmax_rows(s, scale):
     _chk(s, F32, "s")
     rows, cols = s.shape

@@ -15,6 +15,8 @@ import torch
 SD15_UNET_CONFIG = dict(block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, num_heads=8,
                         cross_attention_dim=768, in_channels=4, out_channels=4, groups=32,
                         down_cross=(True, True, True, False), time_cond_proj_dim=None)
+SD15_CLIP_TEXT_CONFIG = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                             vocab_size=49408, max_position_embeddings=77, layer_norm_eps=1e-5, eos_token_id=2)
 SD15_VAE_CONFIG = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
                        in_channels=3, out_channels=3, groups=32, scaling_factor=0.18215)
 
@@ -271,6 +273,30 @@ def vae_spec(cfg=SD15_VAE_CONFIG):
     return spec
 
 
+def clip_text_spec(cfg=SD15_CLIP_TEXT_CONFIG):
+    """transformers `CLIPTextModel` state-dict layout (`<base>/text_encoder/model.safetensors`, validation.py:31-32):
+    ViT-L/14 text tower, 123.06 M parameters at the SD-1.5 config."""
+    spec = OrderedDict()
+    c, f = cfg["hidden_size"], cfg["intermediate_size"]
+    spec["text_model.embeddings.token_embedding.weight"] = ("emb", (cfg["vocab_size"], c))
+    spec["text_model.embeddings.position_embedding.weight"] = ("emb", (cfg["max_position_embeddings"], c))
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"text_model.encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec[p + f"self_attn.{n}.weight"] = ("w", (c, c))
+            spec[p + f"self_attn.{n}.bias"] = ("b", (c,))
+        for n in ("layer_norm1", "layer_norm2"):
+            spec[p + n + ".weight"] = ("norm_w", (c,))
+            spec[p + n + ".bias"] = ("norm_b", (c,))
+        spec[p + "mlp.fc1.weight"] = ("w", (f, c))
+        spec[p + "mlp.fc1.bias"] = ("b", (f,))
+        spec[p + "mlp.fc2.weight"] = ("w", (c, f))
+        spec[p + "mlp.fc2.bias"] = ("b", (c,))
+    spec["text_model.final_layer_norm.weight"] = ("norm_w", (c,))
+    spec["text_model.final_layer_norm.bias"] = ("norm_b", (c,))
+    return spec
+
+
 # ------------------------------------------------------------------------------------- synthetic weights
 def synthesize(spec, seed=0, bf16_round=True, gain=1.0):
     """Seeded weights of the given spec: W ~ N(0, gain/fan_in), b ~ N(0, 0.02), norm affine near identity,
@@ -290,7 +316,7 @@ def synthesize(spec, seed=0, bf16_round=True, gain=1.0):
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif kind == "norm_b":
             t = 0.05 * torch.randn(shape, generator=g)
-        elif kind in ("zero_w", "zero_b"):
+        elif kind in ("zero_w", "zero_b", "emb"):
             t = torch.randn(shape, generator=g) * 0.02
         else:
             raise KeyError(kind)

@@ -93,7 +93,7 @@ typedef struct dc_conv_desc {
     float out_scale;
     int splitk;             /* >= 1 */
     int gn_batch;           /* rows of gn_ab (sample n uses row n % gn_batch) */
-    int act;                /* 0 none, 1 SiLU — applied after bias/row_add, before out_scale */
+    int act;                /* 0 none, 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) — applied after bias/row_add, before out_scale */
     long long row_add_stride; /* floats between consecutive samples of row_add (0 = Cout) */
 } dc_conv_desc;
 int dc_conv_igemm_bf16(const dc_conv_desc* desc, void* stream);
@@ -136,6 +136,14 @@ int dc_layernorm_bf16(const void* x, const float* gamma, const float* beta, void
 int dc_attention_bf16(const void* q, const void* k, const void* v, void* out, int B, int heads, int Nq, int Nk, int D,
                       long long q_stride, long long k_stride, long long v_stride, long long o_stride, float scale,
                       void* stream);
+/* Causal softmax(Q K^T * scale) V over a short context (T <= 128, D <= 128): CLIPTextModel self-attention behind
+ * `encode_prompt` (pipeline.py:223-236).  Same operand layout as dc_attention_bf16; key j is visible to query i iff j <= i. */
+int dc_attention_causal_small_bf16(const void* q, const void* k, const void* v, void* out, int B, int heads, int T, int D,
+                                   long long q_stride, long long k_stride, long long v_stride, long long o_stride,
+                                   float scale, void* stream);
+/* CLIPTextEmbeddings: out[b][t][:] = tok_emb[ids[b][t]][:] + pos_emb[t][:]  (ids int64 [B][T]; tables and out bf16). */
+int dc_embed_tokens_bf16(const long long* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int T, int C,
+                         int vocab, void* stream);
 /* Row softmax fp32 -> bf16 (VAE single-head attention, d=512, done as GEMM/softmax/GEMM). */
 int dc_softmax_rows_f32_to_bf16(const float* s, void* p, long long rows, int cols, float scale, void* stream);
 

@@ -1,0 +1,117 @@
+"""GPU parity of the CLIP text tower behind `encode_prompt` (reference pipeline.py:223-236) against the CPU oracle
+(oracle/clip_ref.py, itself pinned to transformers' CLIPTextModel by tests/test_oracle_clip.py), and of the pipeline's
+`prompt=` path.  Device path: bf16 activations, fp32 accumulation; tolerance is a relative L2 stated per test."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SMALL = dict(hidden_size=128, num_hidden_layers=3, num_attention_heads=4, intermediate_size=256, vocab_size=1000,
+             max_position_embeddings=77, layer_norm_eps=1e-5, eos_token_id=2)
+
+
+def _ids(cfg, b, seed=0, t=None):
+    t = cfg["max_position_embeddings"] if t is None else t
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, cfg["vocab_size"] - 1, (b, t), generator=g)
+    ids[:, 0] = 0
+    for i in range(b):
+        e = min(t - 2, 5 + 7 * i)
+        ids[i, e:] = cfg["vocab_size"] - 1
+    return ids
+
+
+def _rel(a, b):
+    return ((a.float().cpu() - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("cfg_name,b,t", [("small", 3, 77), ("small", 1, 20), ("sd15", 2, 77)])
+def test_text_tower_vs_oracle(cfg_name, b, t):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import weights
+    from diffcodec_amd.text_encoder import HipCLIPTextModel
+    from oracle import clip_ref
+    cfg = SMALL if cfg_name == "small" else dict(weights.SD15_CLIP_TEXT_CONFIG)
+    sd = weights.synthesize(weights.clip_text_spec(cfg), seed=3, gain=2.0)
+    ids = _ids(cfg, b, t=t)
+    ref_last, ref_pool, ref_hidden = clip_ref.clip_text_forward(sd, cfg, ids, output_hidden_states=True)
+    te = HipCLIPTextModel(sd, cfg, DEV)
+    out = te(ids, output_hidden_states=True)
+    assert out[0].shape == ref_last.shape and out[0].dtype == torch.bfloat16
+    assert _rel(out.last_hidden_state, ref_last) < 2e-2              # 12 bf16 layers against fp32
+    assert _rel(out.pooler_output, ref_pool) < 2e-2
+    assert len(out.hidden_states) == len(ref_hidden)
+    assert _rel(out.hidden_states[1], ref_hidden[1]) < 1e-2          # one layer in: bf16 rounding only
+    # clip_skip path of encode_prompt: final_layer_norm applied to an earlier hidden state
+    ln = te.text_model.final_layer_norm(out[-1][-2])
+    import torch.nn.functional as F
+    c = cfg["hidden_size"]
+    ref_ln = F.layer_norm(ref_hidden[-2], (c,), sd["text_model.final_layer_norm.weight"], sd["text_model.final_layer_norm.bias"], 1e-5)
+    assert _rel(ln, ref_ln) < 2e-2
+
+
+def test_causality_and_errors():
+    """Token t's output must not depend on tokens after t (the causal mask), and bad ids / masks fail loudly."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import weights
+    from diffcodec_amd.text_encoder import HipCLIPTextModel
+    sd = weights.synthesize(weights.clip_text_spec(SMALL), seed=3, gain=2.0)
+    te = HipCLIPTextModel(sd, SMALL, DEV)
+    a = _ids(SMALL, 2, seed=1)
+    b = a.clone()
+    b[:, 40:] = 7
+    oa, ob = te(a)[0], te(b)[0]
+    assert torch.equal(oa[:, :40], ob[:, :40])
+    assert not torch.equal(oa[:, 40:], ob[:, 40:])
+    with pytest.raises(IndexError):
+        te(torch.full((1, 77), 5000))
+    with pytest.raises(NotImplementedError):
+        te(a, attention_mask=torch.ones_like(a))
+    with pytest.raises(ValueError):
+        te(torch.zeros(1, 78, dtype=torch.long))
+
+
+class _Tok:
+    """Stand-in for CLIPTokenizer (its vocabulary files are not reachable offline): deterministic ids per string, BOS,
+    EOS-padded to model_max_length — the layout `tokenizer(..., padding="max_length")` produces."""
+    model_max_length = 77
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def __call__(self, texts, padding=None, max_length=None, truncation=None, return_tensors=None):
+        from types import SimpleNamespace
+        rows = []
+        for s in texts:
+            body = [3 + (ord(ch) * 31 + i) % (self.vocab - 5) for i, ch in enumerate(s)][: max_length - 2]
+            rows.append([0] + body + [self.vocab - 1] * (max_length - 1 - len(body)))
+        return SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.long))
+
+
+def test_pipeline_prompt_path_equals_prompt_embeds():
+    """pipeline.py:223-236: `prompt=` (+ default negative "") through the HIP text tower gives the same frame as passing
+    the tower's own embeddings as `prompt_embeds=`; and the embeddings agree with the oracle's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import selftest as T, weights
+    from diffcodec_amd.synthetic import synth_controls, synth_latents
+    from diffcodec_amd.text_encoder import HipCLIPTextModel
+    from oracle import clip_ref
+    cfg = dict(SMALL, hidden_size=T.SMALL_UNET["cross_attention_dim"], num_attention_heads=2)
+    cfg["intermediate_size"] = 2 * cfg["hidden_size"]
+    sd = weights.synthesize(weights.clip_text_spec(cfg), seed=5, gain=2.0)
+    pipe, _ = T.build_small_pipeline()
+    pipe.text_encoder, pipe.tokenizer = HipCLIPTextModel(sd, cfg, DEV), _Tok(cfg["vocab_size"])
+    cond, flow = synth_controls(1, 256)
+    lat = synth_latents(1, 256)
+    kw = dict(controlnet_cond=cond, flow_cond=flow, latents=lat, num_inference_steps=2, guidance_scale=4.5, output_type="pt")
+    a = pipe(prompt="a video frame", **kw).images.float().cpu()
+    tok = pipe.tokenizer(["a video frame", ""], max_length=77)
+    emb = pipe.text_encoder(tok.input_ids)[0]
+    ref = clip_ref.clip_text_forward(sd, cfg, tok.input_ids)[0]
+    assert _rel(emb, ref) < 2e-2
+    b = pipe(prompt_embeds=emb[:1], negative_prompt_embeds=emb[1:], **kw).images.float().cpu()
+    assert T.psnr(a, b) > 40.0        # not bit-equal: the splat's atomic arrival order and M-dependent split-K differ per run
