@@ -210,6 +210,42 @@ __global__ void vae_sample_kernel(const float* __restrict__ mom, const float* __
     }
 }
 
+// ---- input side (controlnet/utils.py:21-39).  The .flo payload is [H][W][2] fp32 and PIL images are [H][W][3] uint8:
+// both are read in their file layout and written as NCHW fp32 planes of the control tensors, so the host only uploads
+// the raw bytes.
+// resize_flow_to: F.interpolate(bilinear, align_corners=True) then u *= tw/W, v *= th/H (fp32 scalars, as torch's
+// in-place mul by a Python float).  Index arithmetic follows ATen's area_pixel_compute_source_index in fp32.
+__global__ void flow_hw2_resize_kernel(const float* __restrict__ src, int H, int W, float* __restrict__ dst, int th, int tw,
+                                       float mul_u, float mul_v, float sy, float sx)
+{
+#pragma clang fp contract(off)   // the source index must be the ROUNDED product (ATen): an fma into the lambda shifts it by 1/2 ulp(index)
+    const long long total = (long long)th * tw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / tw), x = (int)(i - (long long)y * tw);
+        const float fy = sy * (float)y, fx = sx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float2 a = *(const float2*)(src + ((long long)y0 * W + x0) * 2), b = *(const float2*)(src + ((long long)y0 * W + x1) * 2);
+        const float2 c = *(const float2*)(src + ((long long)y1 * W + x0) * 2), e = *(const float2*)(src + ((long long)y1 * W + x1) * 2);
+        dst[i] = (hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * e.x)) * mul_u;
+        dst[total + i] = (hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * e.y)) * mul_v;
+    }
+}
+
+// TF.to_tensor + torch.cat of load_pair_to_sixch: dst[c][y][x] = img0[y][x][c] / 255, dst[3 + c] from img1
+__global__ void pack_sixch_kernel(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, float* __restrict__ dst,
+                                  long long HW)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dst[c * HW + i] = (float)img0[i * 3 + c] / 255.0f;
+            dst[(3 + c) * HW + i] = (float)img1[i * 3 + c] / 255.0f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream)
@@ -320,5 +356,24 @@ extern "C" int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t
     if (!x || (!out_nchw_f32 && !out_nhwc_u8)) return DC_ERR_INVALID;
     const long long total = (long long)N * C * H * W;
     hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out_nchw_f32, out_nhwc_u8, C, (long long)H * W, total);
+    return dc_launch_status();
+}
+
+extern "C" int dc_flow_hw2_resize_scale_f32(const float* src_hw2, int H, int W, float* dst_2hw, int th, int tw, void* stream)
+{
+    if (!src_hw2 || !dst_2hw || H <= 0 || W <= 0 || th <= 0 || tw <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(flow_hw2_resize_kernel, dim3(grid_for((long long)th * tw)), dim3(256), 0, (hipStream_t)stream, src_hw2, H, W,
+                       dst_2hw, th, tw, (float)((double)tw / (double)W), (float)((double)th / (double)H),
+                       // source-index scales in IEEE fp32 on the host (ATen's area_pixel_compute_scale<float>): a 1-ulp
+                       // error here is amplified by the pixel index
+                       th > 1 ? (float)(H - 1) / (float)(th - 1) : 0.f, tw > 1 ? (float)(W - 1) / (float)(tw - 1) : 0.f);
+    return dc_launch_status();
+}
+
+extern "C" int dc_pack_sixch_u8_f32(const uint8_t* img0_hw3, const uint8_t* img1_hw3, float* dst_6hw, int H, int W, void* stream)
+{
+    if (!img0_hw3 || !img1_hw3 || !dst_6hw || H <= 0 || W <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(pack_sixch_kernel, dim3(grid_for((long long)H * W)), dim3(256), 0, (hipStream_t)stream, img0_hw3, img1_hw3,
+                       dst_6hw, (long long)H * W);
     return dc_launch_status();
 }

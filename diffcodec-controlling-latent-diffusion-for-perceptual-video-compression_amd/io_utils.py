@@ -6,8 +6,10 @@
     load_pair_to_sixch        utils.py:30-39   two RGB images (PIL, BICUBIC resize) -> [1,6,H,W] in [0,1]
     load_controls_and_flows   utils.py:41-52   -> (controlnet_cond [1,6,H,W], flow_cond [1,4,H,W]) on `device`
 
-Host-side file I/O and preparation (the reference does the same on the CPU and then moves the tensors); the
-only dependency dropped is torchvision (`TF.to_tensor` is restated: HWC uint8 -> CHW float32 / 255)."""
+File I/O and the PIL resize stay on the host, as in the reference.  With a GPU `device`, `load_controls_and_flows` uploads
+the raw bytes (uint8 images, the .flo payload) and does the float conversion, 6-channel packing, flow resize and vector
+rescale as C-ABI launches; with `device="cpu"` it is the reference's host arithmetic.  The only
+dependency dropped is torchvision (`TF.to_tensor` is restated: HWC uint8 -> CHW float32 / 255)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -45,25 +47,33 @@ def resize_flow_to(flow_hw2: np.ndarray, target_h: int, target_w: int) -> torch.
 
 
 def _to_tensor(img) -> torch.Tensor:
-    a = np.asarray(img, dtype=np.uint8)
+    a = np.array(img, dtype=np.uint8)          # a writable copy (PIL exposes a read-only buffer)
     return torch.from_numpy(a).permute(2, 0, 1).float().div(255.0)
 
 
-def load_pair_to_sixch(path0, path1, size=(512, 512)) -> torch.Tensor:
+def _load_rgb_u8(p, size):
     from PIL import Image
+    img = Image.open(p).convert("RGB")
+    if size is not None:
+        img = img.resize(size, Image.BICUBIC)
+    return np.array(img, dtype=np.uint8)
 
-    def load_rgb(p):
-        img = Image.open(p).convert("RGB")
-        if size is not None:
-            img = img.resize(size, Image.BICUBIC)
-        return _to_tensor(img)
 
-    return torch.cat([load_rgb(path0), load_rgb(path1)], dim=0).unsqueeze(0)
+def load_pair_to_sixch(path0, path1, size=(512, 512)) -> torch.Tensor:
+    return torch.cat([_to_tensor(_load_rgb_u8(path0, size)), _to_tensor(_load_rgb_u8(path1, size))], dim=0).unsqueeze(0)
 
 
 def load_controls_and_flows(img0_path, img1_path, fwd_flo_path, bwd_flo_path, size=(512, 512), device="cuda",
                             dtype=torch.float32):
     h, w = size
+    if torch.device(device).type == "cuda":
+        from . import ops
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+        sixch = ops.pack_sixch(up(_load_rgb_u8(img0_path, size)), up(_load_rgb_u8(img1_path, size)))
+        flow4 = torch.empty((1, 4, h, w), device=device, dtype=torch.float32)
+        ops.flow_hw2_resize_scale(up(read_flo(fwd_flo_path)), h, w, out=flow4[0, :2])
+        ops.flow_hw2_resize_scale(up(read_flo(bwd_flo_path)), h, w, out=flow4[0, 2:])
+        return sixch.to(dtype), flow4.to(dtype)
     sixch = load_pair_to_sixch(img0_path, img1_path, size=size).to(device=device, dtype=dtype)
     fwd_t = resize_flow_to(read_flo(fwd_flo_path), h, w)
     bwd_t = resize_flow_to(read_flo(bwd_flo_path), h, w)

@@ -63,6 +63,8 @@ SIGNATURES = {
     "dc_cfg_ddim_step": [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_latents_to_model_input": [vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_postprocess_image": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "dc_flow_hw2_resize_scale_f32": [vp, i32, i32, vp, i32, i32, vp],
+    "dc_pack_sixch_u8_f32": [vp, vp, vp, i32, i32, vp],
 }
 
 _lib = None

@@ -502,3 +502,27 @@ def postprocess_image(x_nhwc_f32, want_u8=False):
     o8 = torch.empty((n, h, w, c), device=x_nhwc_f32.device, dtype=torch.uint8) if want_u8 else None
     lib.call("dc_postprocess_image", x_nhwc_f32.data_ptr(), o32.data_ptr(), _ptr(o8), n, c, h, w, _stream())
     return o32, o8
+
+
+# ------------------------------------------------------------------------------------------ input side
+def flow_hw2_resize_scale(flow_hw2, th, tw, out=None):
+    """resize_flow_to (controlnet/utils.py:21-28) on the device: [H,W,2] fp32 (.flo payload layout) -> [2,th,tw] fp32."""
+    _chk(flow_hw2, F32, "flow_hw2")
+    h, w, two = flow_hw2.shape
+    assert two == 2
+    if out is None:
+        out = torch.empty((2, th, tw), device=flow_hw2.device, dtype=F32)
+    assert out.shape == (2, th, tw) and out.dtype == F32 and out.is_contiguous()
+    lib.call("dc_flow_hw2_resize_scale_f32", flow_hw2.data_ptr(), h, w, out.data_ptr(), th, tw, _stream())
+    return out
+
+
+def pack_sixch(img0_u8, img1_u8):
+    """load_pair_to_sixch's tensor half (utils.py:36-39): two [H,W,3] uint8 images -> [1,6,H,W] fp32 in [0,1]."""
+    for t in (img0_u8, img1_u8):
+        assert t.dtype == torch.uint8 and t.is_cuda and t.is_contiguous() and t.dim() == 3 and t.shape[2] == 3
+    assert img0_u8.shape == img1_u8.shape
+    h, w, _ = img0_u8.shape
+    out = torch.empty((1, 6, h, w), device=img0_u8.device, dtype=F32)
+    lib.call("dc_pack_sixch_u8_f32", img0_u8.data_ptr(), img1_u8.data_ptr(), out.data_ptr(), h, w, _stream())
+    return out

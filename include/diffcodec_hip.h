@@ -177,6 +177,14 @@ int dc_latents_to_model_input(const float* latents, void* model_in, float mul, i
 /* image_processor.postprocess — pipeline.py:397-398: (x/2+0.5).clamp(0,1); x NHWC f32 [N,H,W,3] -> NCHW f32 and/or NHWC u8 */
 int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------ input side (controlnet/utils.py) */
+/* resize_flow_to (utils.py:21-28) on the .flo payload layout: src [H][W][2] fp32 (pixel units) -> dst [2][th][tw] fp32,
+ * bilinear with align_corners=True, then u *= tw/W and v *= th/H. */
+int dc_flow_hw2_resize_scale_f32(const float* src_hw2, int H, int W, float* dst_2hw, int th, int tw, void* stream);
+/* load_pair_to_sixch (utils.py:30-39) after the PIL resize: two RGB uint8 [H][W][3] images -> [6][H][W] fp32 in [0,1]
+ * (TF.to_tensor's x/255, image 0 in planes 0-2, image 1 in planes 3-5). */
+int dc_pack_sixch_u8_f32(const uint8_t* img0_hw3, const uint8_t* img1_hw3, float* dst_6hw, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

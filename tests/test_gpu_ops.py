@@ -318,11 +318,56 @@ def test_layout_and_timestep_embedding(ops):
 def test_conv_tile_two_images_per_tile(ops):
     """8x8 maps, even batch, enough tiles: the 8-row tile shape carries two whole images (wave row = image)."""
     g = torch.Generator().manual_seed(15)
-    n, cin, cout = 8, 640, 1280
+    n, cin, cout = 16, 640, 1280
     x = bf(torch.randn(n, cin, 8, 8, generator=g))
     wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
     b = torch.randn(cout, generator=g) * 0.1
     temb = torch.randn(n, cout, generator=g)
     ref = F.conv2d(x, wt, b, padding=1) + temb[:, :, None, None]
-    out = ops.conv(nhwc(x), ops.PackedConv(wt, b, DEV), row_add=temb.to(DEV), splitk=16)     # (8/2) * 8 N-tiles * 16 = 512 workgroups
+    out = ops.conv(nhwc(x), ops.PackedConv(wt, b, DEV), row_add=temb.to(DEV), splitk=10)     # (16/2) * 8 N-tiles * 10 splits = 640 workgroups >= 512
     close(from_nhwc(out), ref)
+
+
+# ------------------------------------------------------------------------------------------- input side
+@pytest.mark.parametrize("hw,target", [((270, 480), (512, 512)), ((512, 512), (512, 512)), ((64, 96), (33, 1)), ((1, 7), (5, 9))])
+def test_flow_hw2_resize_scale(ops, hw, target):
+    """resize_flow_to (controlnet/utils.py:21-28) restated with the same torch calls on the CPU vs the device kernel.
+    fp32 both sides; tolerance covers fma contraction only."""
+    g = torch.Generator().manual_seed(16)
+    h, w = hw
+    th, tw = target
+    flow = torch.randn(h, w, 2, generator=g) * 6
+    ft = F.interpolate(flow.permute(2, 0, 1).unsqueeze(0), size=(th, tw), mode="bilinear", align_corners=True)
+    ft[:, 0] *= (tw / max(w, 1))
+    ft[:, 1] *= (th / max(h, 1))
+    out = ops.flow_hw2_resize_scale(flow.to(DEV), th, tw).cpu()
+    close(out, ft[0], rtol=1e-5, atol=1e-5)
+
+
+def test_pack_sixch_bit_exact(ops):
+    """TF.to_tensor + cat of load_pair_to_sixch (utils.py:36-39): uint8 -> x/255 is bit-exact."""
+    g = torch.Generator().manual_seed(17)
+    a = torch.randint(0, 256, (37, 53, 3), generator=g, dtype=torch.uint8)
+    b = torch.randint(0, 256, (37, 53, 3), generator=g, dtype=torch.uint8)
+    ref = torch.cat([a.permute(2, 0, 1).float().div(255.0), b.permute(2, 0, 1).float().div(255.0)], 0).unsqueeze(0)
+    assert torch.equal(ops.pack_sixch(a.to(DEV), b.to(DEV)).cpu(), ref)
+
+
+def test_load_controls_and_flows_device_path_equals_host_path(tmp_path):
+    """utils.py:41-52: the GPU preprocessing path against the host path of the same loader on the same files."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    from PIL import Image
+    from diffcodec_amd import io_utils
+    rng = np.random.default_rng(0)
+    for name in ("a.png", "b.png"):
+        Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)).save(tmp_path / name)
+    for name in ("f.flo", "b.flo"):
+        io_utils.write_flo(str(tmp_path / name), rng.normal(0, 5, (135, 240, 2)).astype(np.float32))
+    args = [str(tmp_path / n) for n in ("a.png", "b.png", "f.flo", "b.flo")]
+    c_ref, f_ref = io_utils.load_controls_and_flows(*args, size=(512, 512), device="cpu")
+    c_dev, f_dev = io_utils.load_controls_and_flows(*args, size=(512, 512), device=DEV)
+    assert c_dev.shape == (1, 6, 512, 512) and f_dev.shape == (1, 4, 512, 512)
+    assert torch.equal(c_dev.cpu(), c_ref)
+    close(f_dev.cpu(), f_ref, rtol=1e-5, atol=1e-5)
