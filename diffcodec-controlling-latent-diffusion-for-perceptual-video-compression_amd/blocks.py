@@ -40,9 +40,9 @@ class TimeEmbedding:
         self.all = ops.linear(e, self.proj, out_f32=True)       # [n, total]
         return self
 
-    def slice(self, prefix):
+    def slice(self, prefix, rows=None):
         a, b = self.slices[prefix]
-        return self.all[:, a:b]
+        return self.all[:rows, a:b]
 
 
 class ResnetBlock:
@@ -62,7 +62,7 @@ class ResnetBlock:
 
     def __call__(self, x, temb=None, x2=None):
         ab1 = ops.group_norm_ab(x, self.n1[0], self.n1[1], self.groups, self.eps, x2=x2)
-        h = ops.conv_gn_silu(x, self.conv1, ab1, x2=x2, row_add=None if temb is None else temb.slice(self.p))
+        h = ops.conv_gn_silu(x, self.conv1, ab1, x2=x2, row_add=None if temb is None else temb.slice(self.p, x.shape[0]))
         ab2 = ops.group_norm_ab(h, self.n2[0], self.n2[1], self.groups, self.eps)
         if self.shortcut is not None:
             sc = ops.conv(x, self.shortcut, x2=x2)
@@ -102,7 +102,11 @@ class TransformerBlock:
         else:
             self.kv_ctx = new
 
-    def __call__(self, x):
+    def __call__(self, x, cfg_shared=False):
+        """cfg_shared: x is ONE half [B] of a classifier-free-guidance batch whose two halves are identical up to here
+        (same latents, same timestep; pipeline.py:313-320 duplicates them).  Everything before the text cross-attention
+        is then the same for both halves and is computed once; the halves separate at attn2's K/V (the contexts
+        [uncond | cond] of `set_context`).  Returns the full [2B] batch.  Same values as running the duplicated batch."""
         n, h, w, c = x.shape
         ab = ops.group_norm_ab(x, self.norm[0], self.norm[1], self.groups, 1e-6)
         t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
@@ -114,13 +118,30 @@ class TransformerBlock:
         # cross-attention
         y = ops.layer_norm(t, *self.ln[1])
         q = ops.linear(y, self.q2)
-        a = ops.attention(q, self.kv_ctx[..., :c], self.kv_ctx[..., c:], self.heads)
-        t = ops.linear(a, self.out2, residual=t)
+        kv = self.kv_ctx
+        if not cfg_shared:
+            a = ops.attention(q, kv[..., :c], kv[..., c:], self.heads)
+            t = ops.linear(a, self.out2, residual=t)
+        else:
+            assert kv.shape[0] == 2 * n, "cfg_shared needs the [uncond | cond] context batch"
+            a = torch.empty((2 * n, h * w, c), device=x.device, dtype=x.dtype)
+            t2 = torch.empty_like(a)
+            for half in (0, 1):                                  # same queries and residual, that half's text keys/values
+                sl = slice(half * n, (half + 1) * n)
+                ops.attention(q, kv[sl, :, :c], kv[sl, :, c:], self.heads, out=a[sl])
+                ops.linear(a[sl], self.out2, residual=t, out=t2[sl])
+            t = t2
         # GEGLU feed-forward
         y = ops.layer_norm(t, *self.ln[2])
         f = ops.linear(y, self.ff1)
         t = ops.linear(f, self.ff2, residual=t)
-        return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x)
+        if not cfg_shared:
+            return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x)
+        out = torch.empty((2 * n, h, w, c), device=x.device, dtype=x.dtype)
+        for half in (0, 1):
+            sl = slice(half * n, (half + 1) * n)
+            ops.conv(t[sl].reshape(n, h, w, c), self.proj_out, residual=x, out=out[sl])
+        return out
 
 
 class EncoderHalf:
@@ -157,10 +178,17 @@ class EncoderHalf:
                     yield a
         yield self.mid_attn
 
-    def run_down(self, sample, temb, after_block=None):
+    def run_down(self, sample, temb, after_block=None, cfg_shared=False):
+        """cfg_shared: the two batch halves of `sample` are identical (classifier-free guidance: duplicated latents, one
+        timestep): the first resnet and the first transformer up to its text cross-attention run on one half only."""
         res = [sample]
+        shared = cfg_shared and self.down[0]["attns"][0] is not None and sample.shape[0] % 2 == 0
         for i, blk in enumerate(self.down):
-            for r, a in zip(blk["resnets"], blk["attns"]):
+            for j, (r, a) in enumerate(zip(blk["resnets"], blk["attns"])):
+                if shared and i == 0 and j == 0:
+                    sample = a(r(sample[: sample.shape[0] // 2], temb), cfg_shared=True)
+                    res.append(sample)
+                    continue
                 sample = r(sample, temb)
                 if a is not None:
                     sample = a(sample)

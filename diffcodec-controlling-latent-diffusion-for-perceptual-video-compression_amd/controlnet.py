@@ -147,7 +147,7 @@ class HipDualFlowControlNet:
         ab = ops.group_norm_ab(sample, None, None, self.cfg["groups"], 1e-5)
         return ops.fdn_modulate(sample, ab, gamma, beta)
 
-    def forward_nhwc(self, x, t_dev, conditioning_scale=1.0, step_dev=None):
+    def forward_nhwc(self, x, t_dev, conditioning_scale=1.0, step_dev=None, cfg_shared=False):
         """x NHWC bf16 [n,h,w,4] -> (12 residuals, mid) NHWC bf16.  Needs set_context + prepare_controls first."""
         enc = self.enc
         temb = enc.temb(t_dev, x.shape[0], step_dev)
@@ -157,7 +157,7 @@ class HipDualFlowControlNet:
         def hook(i, s):                                                     # :98-106 — fdn08 twice, residuals pre-FDN
             return self._fdn(s, min(i + 1, 3))
 
-        sample, res = enc.run_down(sample, temb, after_block=hook)
+        sample, res = enc.run_down(sample, temb, after_block=hook, cfg_shared=cfg_shared)
         sample = enc.run_mid(sample, temb)                                  # :112-118
         down = [ops.conv(r, z, out_scale=conditioning_scale) for r, z in zip(res, self.zero)]   # :120-128
         mid = ops.conv(sample, self.zero_mid, out_scale=conditioning_scale)

@@ -100,8 +100,9 @@ def _pick_splitk(m, cout, kt, units=None):
 
 
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
-         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0):
-    """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`."""
+         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None):
+    """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`.  `out`: optional preallocated
+    contiguous destination (e.g. one batch half of a larger buffer) on the igemm path."""
     _chk(x1, BF16, "x1")
     n, h, w, c1 = x1.shape
     c2 = 0
@@ -118,7 +119,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         ho = (hin + (2 if pad else 1) - 3) // stride + 1
         wo = (win + (2 if pad else 1) - 3) // stride + 1
     if pc.kind == "small_cin":
-        assert x2 is None and gn_ab is None and residual is None and row_add is None and not upsample and not out_f32
+        assert x2 is None and gn_ab is None and residual is None and row_add is None and not upsample and not out_f32 and out is None
         out = torch.empty((n, ho, wo, pc.cout), device=x1.device, dtype=BF16)
         lib.call("dc_conv_small_cin_bf16", x1.data_ptr(), pc.w.data_ptr(), _ptr(pc.bias), out.data_ptr(), n, h, w, c1,
                  pc.cout, k, stride, pad if k == 3 else 0, ho, wo, _stream())
@@ -126,14 +127,18 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
             raise ValueError("out_scale unsupported on the small-cin path")
         return out
     if pc.kind == "small_cout":
-        assert x2 is None and residual is None and row_add is None and not upsample and stride == 1 and (k == 1 or pad == 1)
+        assert x2 is None and residual is None and row_add is None and not upsample and stride == 1 and (k == 1 or pad == 1) and out is None
         out = torch.empty((n, h, w, pc.cout), device=x1.device, dtype=F32 if out_f32 else BF16)
         gb = 0 if gn_ab is None else gn_ab.shape[0]
         lib.call("dc_conv_small_cout_bf16", x1.data_ptr(), pc.w.data_ptr(), _ptr(pc.bias), _ptr(gn_ab), int(gn_silu), gb,
                  out.data_ptr(), int(out_f32), n, h, w, c1, pc.cout, k, _stream())
         return out
     cout_eff = pc.cout // 2 if pc.geglu else pc.cout
-    out = torch.empty((n, ho, wo, cout_eff), device=x1.device, dtype=F32 if out_f32 else BF16)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout_eff), device=x1.device, dtype=F32 if out_f32 else BF16)
+    else:
+        assert out.is_contiguous() and out.numel() == n * ho * wo * cout_eff and out.dtype == (F32 if out_f32 else BF16)
+        out = out.view(n, ho, wo, cout_eff)
     m = n * ho * wo
     kt = (9 if k == 3 else 1) * (pc.cin // 64)
     if splitk is None:
@@ -264,14 +269,16 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------ attention
-def attention(q, k, v, heads, scale=None):
+def attention(q, k, v, heads, scale=None, out=None):
     """q [B,Nq,*] k,v [B,Nk,*] bf16 row-strided views (last-dim slices of a fused projection are fine)."""
     b, nq, c = q.shape
     nk = k.shape[1]
     d = c // heads
     for t in (q, k, v):
         assert t.dtype == BF16 and t.is_cuda and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1)
-    out = torch.empty((b, nq, c), device=q.device, dtype=BF16)
+    if out is None:
+        out = torch.empty((b, nq, c), device=q.device, dtype=BF16)
+    assert out.shape == (b, nq, c) and out.dtype == BF16 and out.is_contiguous()
     lib.call("dc_attention_bf16", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), b, heads, nq, nk, d,
              q.stride(1), k.stride(1), v.stride(1), out.stride(1), float(scale if scale is not None else d ** -0.5), _stream())
     return out

@@ -66,6 +66,7 @@ class StableDiffusionDualFlowControlNetPipeline:
         self._progress = True
         self._use_graphs = False
         self._dual_stream = False
+        self._cfg_shared = True
         self._graphs = {}
         self._state = {}
         self.device = getattr(unet, "device", torch.device("cuda"))
@@ -93,6 +94,12 @@ class StableDiffusionDualFlowControlNetPipeline:
 
     def enable_hip_graphs(self, flag=True):
         self._use_graphs = bool(flag)
+
+    def enable_cfg_shared_prefix(self, flag=True):
+        """Compute the layers ahead of the first text cross-attention once for both classifier-free-guidance halves
+        (fused loop only; exact: the halves are bitwise identical up to there)."""
+        self._cfg_shared = bool(flag)
+        self._graphs.clear()
 
     def enable_dual_stream(self, flag=True):
         """Run the ControlNet and the UNet down path of each step concurrently on two HIP streams (fused loop only)."""
@@ -312,10 +319,14 @@ class StableDiffusionDualFlowControlNetPipeline:
         coef, ttab = sched.device_tables(device)
         ops.latents_to_model_input(st["lat"], 1.0, 2 if do_cfg else 1, out=st["x_in"])
 
+        # CFG duplicates the latents (pipeline.py:313-320): the two batch halves only separate at the first text
+        # cross-attention, so the layers before it are computed once (same values, see TransformerBlock.__call__)
+        shared = bool(do_cfg and self._cfg_shared)
+
         def one_step(scale):
             if not self._dual_stream:
-                down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"])
-                eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"])
+                down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared)
+                eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"], cfg_shared=shared)
             else:
                 # The ControlNet and the UNet's down path are independent until the skip additions (flownet.py:83-124 vs
                 # pipeline.py:358-367): two HIP streams, joined before the UNet mid block.  Every tensor crossing streams
@@ -324,8 +335,8 @@ class StableDiffusionDualFlowControlNetPipeline:
                 side = st.setdefault("side_stream", torch.cuda.Stream(device=device))
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"])
-                sample, res, temb = unet.encode_nhwc(st["x_in"], ttab, step_dev=st["step"])
+                    down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared)
+                sample, res, temb = unet.encode_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared)
                 main.wait_stream(side)
                 for t_ in down + [mid]:
                     t_.record_stream(main)

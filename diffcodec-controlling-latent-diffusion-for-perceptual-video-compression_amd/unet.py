@@ -87,13 +87,13 @@ class HipUNet2DConditionModel:
         self._ctx_key = key
         self._ctx_keepalive = ctx
 
-    def encode_nhwc(self, x, t_dev, step_dev=None):
+    def encode_nhwc(self, x, t_dev, step_dev=None, cfg_shared=False):
         """First half (time embedding, conv_in, down blocks): independent of the ControlNet, so the fused pipeline can run
         it on one stream while the ControlNet runs on another.  Returns (sample, skips, temb)."""
         enc = self.enc
         temb = enc.temb(t_dev, x.shape[0], step_dev)
         sample = ops.conv(x, enc.conv_in)
-        sample, res = enc.run_down(sample, temb)
+        sample, res = enc.run_down(sample, temb, cfg_shared=cfg_shared)
         return sample, res, temb
 
     def decode_nhwc(self, sample, res, temb, down_res=None, mid_res=None):
@@ -118,10 +118,10 @@ class HipUNet2DConditionModel:
         ab = ops.group_norm_ab(sample, self.norm_out[0], self.norm_out[1], self.cfg["groups"], 1e-5)
         return ops.conv(sample, self.conv_out, gn_ab=ab, gn_silu=True, out_f32=True)
 
-    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None):
+    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None, cfg_shared=False):
         """x NHWC bf16 [n,h,w,4]; t_dev fp32 device scalar (or table indexed by step_dev); residuals NHWC bf16.
-        Returns eps NHWC fp32 [n,h,w,4]."""
-        sample, res, temb = self.encode_nhwc(x, t_dev, step_dev)
+        cfg_shared: the caller guarantees x[:n/2] == x[n/2:] (see TransformerBlock).  Returns eps NHWC fp32 [n,h,w,4]."""
+        sample, res, temb = self.encode_nhwc(x, t_dev, step_dev, cfg_shared)
         return self.decode_nhwc(sample, list(res), temb, down_res, mid_res)
 
     def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,

@@ -348,3 +348,26 @@ def test_dual_stream_step_equals_single_stream(small):
         pipe.enable_dual_stream(False)
     for x in (a, b, c):
         assert T.psnr(x, base) > 36.0
+
+
+def test_cfg_shared_prefix_equals_duplicated_batch(small):
+    """pipeline.py:313-320 duplicates the latents for classifier-free guidance; the fused loop computes the layers ahead
+    of the first text cross-attention once.  Same frame as running the duplicated batch (bf16 rounding is per row, only
+    M-dependent split-K order may differ), eager and under hipGraphs, at batch 1 and 2."""
+    T, pipe, _ = small
+    for b in (1, 2):
+        cond, flow, pe, npe, lat = _inputs(T, b=b)
+        kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+                  num_inference_steps=3, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+        pipe.enable_cfg_shared_prefix(False)
+        try:
+            base = pipe(**kw).images.float().cpu()
+        finally:
+            pipe.enable_cfg_shared_prefix(True)
+        a = pipe(**kw).images.float().cpu()
+        pipe.enable_hip_graphs(True)
+        try:
+            g = pipe(**kw).images.float().cpu()
+        finally:
+            pipe.enable_hip_graphs(False)
+        assert T.psnr(a, base) > 45.0 and T.psnr(g, base) > 45.0, (b, T.psnr(a, base), T.psnr(g, base))
