@@ -10,6 +10,11 @@ from . import ops
 from .ops import PackedConv
 
 
+# measured (profiles/r01_igemm_shapes_frames16.txt): the GN-on-load 1x1 igemm runs at ~250-350 TFLOP/s, the DMA GEMM at
+# 400-750; the extra elementwise pass only pays for itself below this many rows
+PROJ_IN_FUSE_MIN_ROWS = 65536
+
+
 def _f32(sd, key, device):
     return sd[key].detach().float().contiguous().to(device)
 
@@ -109,7 +114,10 @@ class TransformerBlock:
         [uncond | cond] of `set_context`).  Returns the full [2B] batch.  Same values as running the duplicated batch."""
         n, h, w, c = x.shape
         ab = ops.group_norm_ab(x, self.norm[0], self.norm[1], self.groups, 1e-6)
-        t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
+        if n * h * w > PROJ_IN_FUSE_MIN_ROWS:                    # big maps: GroupNorm applied inside the GEMM's load stage
+            t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
+        else:                                                    # small maps: a separate pass + the LDS-DMA GEMM is faster
+            t = ops.conv(ops.gn_apply(x, ab), self.proj_in).reshape(n, h * w, c)
         # self-attention
         y = ops.layer_norm(t, *self.ln[0])
         qkv = ops.linear(y, self.qkv1)

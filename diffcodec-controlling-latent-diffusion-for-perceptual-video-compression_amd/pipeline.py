@@ -317,6 +317,10 @@ class StableDiffusionDualFlowControlNetPipeline:
         cn.set_context(st["ctx"])
         cn.prepare_controls(cond, flow)                       # hoisted: once per call, at batch B (shared by CFG halves)
         coef, ttab = sched.device_tables(device)
+        if st.get("tables") != (id(sched), sched.table_version):     # new schedule: graphs captured on the old tables are stale
+            self._graphs.clear()
+            st["tables"] = (id(sched), sched.table_version)
+            st["sched_keepalive"] = sched                            # keeps id(sched) unique while the key is in use
         ops.latents_to_model_input(st["lat"], 1.0, 2 if do_cfg else 1, out=st["x_in"])
 
         # CFG duplicates the latents (pipeline.py:313-320): the two batch halves only separate at the first text
@@ -324,7 +328,11 @@ class StableDiffusionDualFlowControlNetPipeline:
         shared = bool(do_cfg and self._cfg_shared)
 
         def one_step(scale):
-            if not self._dual_stream:
+            if scale == 0.0:
+                # controlnet_keep = 0 outside [control_guidance_start, end] (pipeline.py:292-295,354): the reference scales
+                # every residual by 0, so adding them changes nothing — skip the ControlNet for this step
+                eps = unet.forward_nhwc(st["x_in"], ttab, None, None, step_dev=st["step"], cfg_shared=shared)
+            elif not self._dual_stream:
                 down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared)
                 eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"], cfg_shared=shared)
             else:
@@ -350,7 +358,7 @@ class StableDiffusionDualFlowControlNetPipeline:
             if not self._use_graphs:
                 one_step(scale)
                 continue
-            gkey = (scale, float(guidance), id(coef))
+            gkey = (scale, float(guidance), shared, self._dual_stream)
             g = self._graphs.get(gkey)
             if g is None:
                 if i == 0 and not st.get("warm"):

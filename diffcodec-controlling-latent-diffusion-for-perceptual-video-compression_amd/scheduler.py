@@ -61,6 +61,9 @@ class DDIMScheduler:
         """(coef [steps,4] fp32, timesteps [steps] fp32) resident on the device for graph-replayed steps."""
         if self._coef_dev is None or self._coef_dev[0].device != torch.device(device):
             self._coef_dev = (self.coefficients().to(device), self.timesteps.float().to(device))
+            # captured hipGraphs hold raw pointers into these tables: consumers key on this counter, never on id() of the
+            # tensors (a freed table's id can be handed to its successor)
+            self.table_version = getattr(self, "table_version", 0) + 1
         return self._coef_dev
 
     def step(self, model_output, timestep, sample, eta=0.0, generator=None, return_dict=True, **kw):

@@ -371,3 +371,25 @@ def test_cfg_shared_prefix_equals_duplicated_batch(small):
         finally:
             pipe.enable_hip_graphs(False)
         assert T.psnr(a, base) > 45.0 and T.psnr(g, base) > 45.0, (b, T.psnr(a, base), T.psnr(g, base))
+
+
+def test_control_guidance_window_vs_oracle(small):
+    """pipeline.py:292-295,354: controlnet_keep zeroes the residual scale outside [control_guidance_start, end].  The
+    fused loop skips the ControlNet on those steps; the oracle runs it and multiplies by 0, as the reference does."""
+    T, pipe, (usd, csd, vsd) = small
+    from oracle import pipeline_ref as R
+    cond, flow, pe, npe, lat = _inputs(T)
+    common = dict(num_inference_steps=4, guidance_scale=4.5, controlnet_conditioning_scale=1.7,
+                  control_guidance_start=0.25, control_guidance_end=0.75)
+    ref_img, ref_lat = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, return_latents=True, **common)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, output_type="pt", **common)
+    img = pipe(**kw).images.float().cpu()
+    assert T.psnr(img, ref_img) > 30.0
+    full = pipe(**dict(kw, control_guidance_start=0.0, control_guidance_end=1.0)).images.float().cpu()
+    assert T.psnr(img, full) < 45.0                      # the window really changes the result
+    pipe.enable_hip_graphs(True)                         # two graph keys (scale 0 and scale 1.7)
+    try:
+        img_h = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.enable_hip_graphs(False)
+    assert T.psnr(img_h, img) > 45.0
