@@ -4,6 +4,8 @@ re-expressed as sequences of C-ABI launches on NHWC bf16 activations.  Host code
 
 Weight keys are the diffusers state-dict keys; topology follows the published SD-1.5 modules
 as called from controlnet/flownet.py:74-124 and pipeline.py:358-367."""
+import os
+
 import torch
 
 from . import ops
@@ -12,7 +14,7 @@ from .ops import PackedConv
 
 # measured (profiles/r01_igemm_shapes_frames16.txt): the GN-on-load 1x1 igemm runs at ~250-350 TFLOP/s, the DMA GEMM at
 # 400-750; the extra elementwise pass only pays for itself below this many rows
-PROJ_IN_FUSE_MIN_ROWS = 65536
+PROJ_IN_FUSE_MIN_ROWS = int(os.environ.get("DC_PROJ_IN_FUSE_MIN_ROWS", "65536"))
 
 
 def _f32(sd, key, device):

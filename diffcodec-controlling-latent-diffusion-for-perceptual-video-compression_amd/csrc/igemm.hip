@@ -378,7 +378,10 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     if (!d.x1 || !d.w || !d.out) return DC_ERR_INVALID;
     if (d.ksize != 1 && d.ksize != 3) return DC_ERR_INVALID;
     if (Cin <= 0 || (Cin & 63) || (d.C1 & 63) || (d.C2 && !d.x2)) return DC_ERR_INVALID;
-    if (d.Cout <= 0 || (d.Cout & 15)) return DC_ERR_INVALID;
+    // Cout: multiples of 16 everywhere; the halo-tile 3x3 kernel alone also takes multiples of 4 (clamped weight rows,
+    // guarded 4-channel epilogue) — UNet conv_out 320->4 runs there on one mostly empty N-tile instead of on the VALU
+    if (d.Cout <= 0 || (d.Cout & 3)) return DC_ERR_INVALID;
+    if ((d.Cout & 15) && !(dc_conv3x3_tile_supported(d) && !dc_gemm_dma_supported(d) && d.splitk <= 1)) return DC_ERR_INVALID;
     if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Ho <= 0 || d.Wo <= 0) return DC_ERR_INVALID;
     if (d.ksize == 1 && (d.stride != 1 || d.upsample || d.Ho != d.H || d.Wo != d.W)) return DC_ERR_INVALID;
     if (d.ksize == 3) {

@@ -39,7 +39,9 @@ class PackedConv:
     kind 'small_cin':  w bf16 [k*k][Cin][Cout]
     kind 'small_cout': w bf16 [Cout][k*k][Cin]"""
 
-    def __init__(self, weight, bias, device, geglu=False):
+    def __init__(self, weight, bias, device, geglu=False, mfma_small_cout=False):
+        """mfma_small_cout: route a Cout <= 8 (multiple of 4) conv through the MFMA tile kernels anyway — one mostly
+        empty N-tile, still several times faster than the VALU direct conv when M*K is large (UNet conv_out)."""
         w = weight.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -50,12 +52,12 @@ class PackedConv:
         if cin <= 16:
             self.kind = "small_cin"
             wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
-        elif cout <= 8:
+        elif cout <= 8 and not (mfma_small_cout and cout % 4 == 0 and cin % 64 == 0):
             self.kind = "small_cout"
             wp = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
         else:
             self.kind = "igemm"
-            if cin % 64 or cout % 16:
+            if cin % 64 or (cout % 16 and not mfma_small_cout):
                 raise ValueError(f"igemm needs Cin%64==0 and Cout%16==0, got {cin}->{cout}")
             wp = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
             if geglu:

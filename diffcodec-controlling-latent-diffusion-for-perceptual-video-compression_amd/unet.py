@@ -52,7 +52,7 @@ class HipUNet2DConditionModel:
                 blk["up"] = PackedConv(sd[k + ".weight"], sd[k + ".bias"], device)
             self.up.append(blk)
         self.norm_out = (sd["conv_norm_out.weight"].float().to(device), sd["conv_norm_out.bias"].float().to(device))
-        self.conv_out = PackedConv(sd["conv_out.weight"], sd["conv_out.bias"], device)
+        self.conv_out = PackedConv(sd["conv_out.weight"], sd["conv_out.bias"], device, mfma_small_cout=True)
         self._ctx_key = None
         self.freeu = None                      # dict(s1, s2, b1, b2) when enabled (diffusers UNet.enable_freeu)
 

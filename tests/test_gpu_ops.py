@@ -371,3 +371,24 @@ def test_load_controls_and_flows_device_path_equals_host_path(tmp_path):
     assert c_dev.shape == (1, 6, 512, 512) and f_dev.shape == (1, 4, 512, 512)
     assert torch.equal(c_dev.cpu(), c_ref)
     close(f_dev.cpu(), f_ref, rtol=1e-5, atol=1e-5)
+
+
+def test_conv3x3_four_output_channels_on_the_tile_kernel(ops):
+    """UNet conv_out (320 -> 4, GroupNorm+SiLU on load, fp32 out) through the MFMA halo-tile kernel: Cout = 4 is one
+    mostly empty N-tile (clamped weight rows, guarded stores)."""
+    g = torch.Generator().manual_seed(18)
+    n, cin, cout, hw = 2, 320, 4, 32
+    x = bf(torch.randn(n, cin, hw, hw, generator=g))
+    wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5)), wt, b, padding=1)
+    pc = ops.PackedConv(wt, b, DEV, mfma_small_cout=True)
+    assert pc.kind == "igemm"
+    xn = nhwc(x)
+    ab = ops.group_norm_ab(xn, gamma.to(DEV), beta.to(DEV), 32, 1e-5)
+    out = ops.conv(xn, pc, gn_ab=ab, gn_silu=True, out_f32=True)
+    assert out.dtype == torch.float32 and out.shape == (n, hw, hw, cout)
+    close(out.permute(0, 3, 1, 2).cpu(), ref)
+    # the direct small-Cout kernel stays the fallback for shapes the tile kernel does not take
+    assert ops.PackedConv(wt[:3], b[:3], DEV, mfma_small_cout=True).kind == "small_cout"
