@@ -79,10 +79,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise HipLibraryMissing(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+    path = os.environ.get("DC_HIP_LIB", LIB_PATH)            # developer knob: A/B a differently compiled build of the same ABI
+    if not os.path.exists(path):
+        raise HipLibraryMissing(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                                 "There is no CPU fallback on the product path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args
