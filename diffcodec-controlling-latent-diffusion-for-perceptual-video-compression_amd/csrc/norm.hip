@@ -101,6 +101,61 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
+// Small maps (<= 16x16): the whole statistic in ONE launch, one workgroup per (sample, group), reading that group's
+// channels of cat[x1, x2] directly (bf16 pairs; a pixel's group slice is contiguous).  Measured (tools/bench_gn.py):
+// 4-8 us against 8-15 us for the slab + finalize pair at 8x8 / 16x16; slower from 32x32 up (strided reads, few
+// workgroups), where the pair stays.  An atomics + last-workgroup-finalises variant was tried and dropped (fp32 atomics:
+// 24-105 us at 32 samples).
+__global__ __launch_bounds__(256) void gn_direct_kernel(const bf16_t* __restrict__ x1, int C1, const bf16_t* __restrict__ x2,
+                                                        int C2, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ ab, long long HW, int groups, int tp, float inv_count,
+                                                        float eps)
+{
+    __shared__ float red[8];
+    const int C = C1 + C2;
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+    const int cpg = C / groups, g0 = g * cpg;
+    const int a0 = min(g0, C1), a1 = min(g0 + cpg, C1);            // [a0,a1) of source 1
+    const int b0 = max(g0, C1) - C1, b1 = max(g0 + cpg, C1) - C1;  // [b0,b1) of source 2
+    const int j = threadIdx.x % tp, pl = threadIdx.x / tp, pstep = 256 / tp;
+    float s = 0.f, ss = 0.f;
+    auto scan = [&](const bf16_t* __restrict__ x, int Cs, int c0, int c1) {
+        const int npairs = (c1 - c0) >> 1;
+        for (long long p = pl; p < HW; p += pstep) {
+            const bf16_t* row = x + ((long long)n * HW + p) * Cs + c0;
+            for (int q = j; q < npairs; q += tp) {
+                const uint32_t raw = *(const uint32_t*)(row + 2 * q);
+                const float lo = __uint_as_float(raw << 16), hi = __uint_as_float(raw & 0xffff0000u);
+                s += lo + hi;
+                ss += lo * lo + hi * hi;
+            }
+        }
+    };
+    if (a1 > a0) scan(x1, C1, a0, a1);
+    if (b1 > b0) scan(x2, C2, b0, b1);
+    s = dc_wave_sum(s);
+    ss = dc_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = s;
+        red[(threadIdx.x >> 6) * 2 + 1] = ss;
+    }
+    __syncthreads();
+    s = red[0] + red[2] + red[4] + red[6];
+    ss = red[1] + red[3] + red[5] + red[7];
+    const float mean = s * inv_count;
+    const float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (int k = threadIdx.x; k < cpg; k += 256) {
+        const int c = g0 + k;
+        const float ga = gamma ? gamma[c] : 1.f;
+        const float be = beta ? beta[c] : 0.f;
+        float2 o;
+        o.x = rstd * ga;
+        o.y = be - mean * rstd * ga;
+        *(float2*)(ab + ((long long)n * C + c) * 2) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, int C1,
                                                        const bf16_t* __restrict__ x2, int C2,
                                                        const float* __restrict__ ab, bf16_t* __restrict__ y,
@@ -245,6 +300,21 @@ extern "C" int dc_gn_finalize(const float* sums1, int C1, int chunks1, const flo
     const float inv_count = 1.0f / ((float)HW * (float)(C / groups));
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(64), 0, (hipStream_t)stream,
                        sums1, C1, chunks1, sums2, C2, chunks2, gamma, beta, ab, N, groups, inv_count, eps);
+    return dc_launch_status();
+}
+
+extern "C" int dc_gn_direct_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                                      float* ab, int N, long long HW, int groups, float eps, void* stream)
+{
+    const int C = C1 + C2;
+    if (!x1 || !ab || N <= 0 || HW <= 0 || groups <= 0 || C <= 0 || C % groups || (C2 && !x2)) return DC_ERR_INVALID;
+    const int cpg = C / groups;
+    if ((cpg & 1) || (C1 & 1) || (C2 & 1)) return DC_ERR_INVALID;       // bf16 pairs: group and source widths must be even
+    const int npairs = cpg >> 1;
+    const int tp = npairs <= 8 ? 8 : (npairs <= 16 ? 16 : 32);          // lanes per pixel
+    const float inv_count = 1.0f / ((float)HW * (float)cpg);
+    hipLaunchKernelGGL(gn_direct_kernel, dim3(N * groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x1, C1,
+                       (const bf16_t*)x2, C2, gamma, beta, ab, HW, groups, tp, inv_count, eps);
     return dc_launch_status();
 }
 

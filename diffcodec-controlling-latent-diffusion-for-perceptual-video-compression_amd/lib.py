@@ -44,6 +44,7 @@ SIGNATURES = {
     "dc_gn_stats_nhwc_bf16": [vp, vp, i32, i64, i32, vp],
     "dc_gn_stats_chunks": [i64, i32],
     "dc_gn_finalize": [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, i64, f32, vp],
+    "dc_gn_direct_nhwc_bf16": [vp, i32, vp, i32, vp, vp, vp, i32, i64, i32, f32, vp],
     "dc_gn_apply_nhwc_bf16": [vp, i32, vp, i32, vp, vp, i32, i64, i32, vp],
     "dc_fdn_modulate_nhwc_bf16": [vp, vp, vp, vp, vp, i32, i32, i64, i32, vp],
     "dc_layernorm_bf16": [vp, vp, vp, vp, i64, i32, f32, vp],

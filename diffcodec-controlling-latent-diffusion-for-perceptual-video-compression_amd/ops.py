@@ -3,6 +3,7 @@
 Activations are NHWC bf16 tensors of shape [N,H,W,C] (a [B,L,C] token sequence is the same memory with H=1, W=L).
 No arithmetic happens in torch on this path; every function below ends in exactly one or more `lib.call`s."""
 import math
+import os
 
 import torch
 
@@ -12,6 +13,9 @@ from .lib import ConvDesc
 BF16 = torch.bfloat16
 F32 = torch.float32
 PROFILE = None      # dict label -> [count, flops, relaunch closure] filled per igemm launch when set by bench.py
+
+
+GN_DIRECT_MAX_PIXELS = int(os.environ.get("DC_GN_DIRECT_MAX_PIXELS", "256"))   # maps up to 16x16: one-launch GroupNorm statistics
 
 
 def _stream():
@@ -237,6 +241,15 @@ def group_norm_ab(x, gamma, beta, groups, eps, x2=None):
     """GroupNorm statistics of cat[x, x2] folded with the affine into per-(sample,channel) (scale, shift)."""
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    if hw <= GN_DIRECT_MAX_PIXELS and (c + c2) % groups == 0 and ((c + c2) // groups) % 2 == 0 and c % 2 == 0 and c2 % 2 == 0:
+        _chk(x, BF16, "x")
+        if x2 is not None:
+            _chk(x2, BF16, "x2")
+        ab = torch.empty((n, c + c2, 2), device=x.device, dtype=F32)
+        lib.call("dc_gn_direct_nhwc_bf16", x.data_ptr(), c, _ptr(x2), c2, _ptr(gamma), _ptr(beta), ab.data_ptr(), n, hw,
+                 groups, float(eps), _stream())
+        return ab
     return gn_finalize(gn_stats(x), gamma, beta, groups, hw, eps, None if x2 is None else gn_stats(x2))
 
 

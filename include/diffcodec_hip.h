@@ -119,6 +119,11 @@ int dc_gn_stats_nhwc_bf16(const void* x, float* partials, int N, long long HW, i
  * gamma/beta may be NULL (affine=False, FDN). */
 int dc_gn_finalize(const float* sums1, int C1, int chunks1, const float* sums2, int C2, int chunks2, const float* gamma,
                    const float* beta, float* ab, int N, int groups, long long HW, float eps, void* stream);
+/* Same result as dc_gn_stats_nhwc_bf16 (+ a second source) followed by dc_gn_finalize, in one launch: one workgroup
+ * per (sample, group) reads its channels of cat[x1, x2] directly.  For small maps (<= 16x16), where the two dependent
+ * launches dominate.  Group width and C1, C2 must be even. */
+int dc_gn_direct_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                           float* ab, int N, long long HW, int groups, float eps, void* stream);
 /* y = (x*a+b) [SiLU]; x = cat[x1,x2] NHWC bf16. */
 int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int C2, const float* ab, void* y,
                           int N, long long HW, int silu, void* stream);

@@ -234,9 +234,19 @@ def test_group_norm_paths(ops):
         xin = torch.cat([x1, x2], 1) if c2 else x1
         ref = F.silu(F.group_norm(xin, groups, gamma, beta, 1e-5))
         d1, d2 = nhwc(x1), (nhwc(x2) if c2 else None)
-        ab = ops.group_norm_ab(d1, gamma.to(DEV), beta.to(DEV), groups, 1e-5, x2=d2)
-        out = ops.gn_apply(d1, ab, silu=True, x2=d2)
-        close(from_nhwc(out), ref)
+        keep = ops.GN_DIRECT_MAX_PIXELS
+        abs_ = []
+        for limit in (0, 1 << 30):                           # chunk-slab + finalize pair, then the one-launch small-map kernel
+            ops.GN_DIRECT_MAX_PIXELS = limit
+            try:
+                ab = ops.group_norm_ab(d1, gamma.to(DEV), beta.to(DEV), groups, 1e-5, x2=d2)
+            finally:
+                ops.GN_DIRECT_MAX_PIXELS = keep
+            abs_.append(ab)
+            out = ops.gn_apply(d1, ab, silu=True, x2=d2)
+            close(from_nhwc(out), ref)
+        for other in abs_[1:]:
+            close(abs_[0].cpu(), other.cpu(), rtol=1e-4, atol=1e-5)    # same statistic, different summation order
 
 
 def test_fdn_modulate(ops):
