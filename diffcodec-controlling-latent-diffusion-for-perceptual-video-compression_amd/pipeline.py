@@ -367,7 +367,9 @@ class StableDiffusionDualFlowControlNetPipeline:
                     continue
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: the RCCL watchdog thread of a multi-rank job polls events while we capture; in the default
+                # global mode that invalidates the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     one_step(scale)
                 self._graphs[gkey] = g                        # capture does not execute: replay below runs step i
             g.replay()
