@@ -28,6 +28,9 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, "dc_common.h"), os.path.join(os.path.dirname(HERE), "include", "diffcodec_hip.h")]
     jobs = []
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and os.path.exists(LIB) and not _stale(LIB, srcs + hdrs):
+        return LIB                                   # prebuilt and newer than every source (e.g. on the GPU box: objects do not travel)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
