@@ -246,6 +246,42 @@ __global__ void pack_sixch_kernel(const uint8_t* __restrict__ img0, const uint8_
     }
 }
 
+// Tiled-decode blend (the weighting of tiling.merge_ramp, this package's driver policy): gather
+// form, one thread per output pixel, tiles visited in index order with numpy's fp32 op order (mul, mul, add — no fma), so
+// the result equals the host merge bit for bit.  ramp[i] = 0.5 - 0.5 cos(pi (i + 0.5) / feather) is computed by the
+// caller; it is applied on tile edges that lie inside the frame only.
+__global__ void blend_tiles_ramp_kernel(const float* __restrict__ tiles, const int* __restrict__ coords, int T, int C,
+                                        int th, int tw, const float* __restrict__ ramp, int feather,
+                                        uint8_t* __restrict__ out, int H, int W, float scale)
+{
+#pragma clang fp contract(off)
+    const long long total = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int y1 = coords[4 * t], y2 = coords[4 * t + 1], x1 = coords[4 * t + 2], x2 = coords[4 * t + 3];
+            if (y < y1 || y >= y2 || x < x1 || x >= x2) continue;
+            const int ly = y - y1, lx = x - x1, ny = y2 - y1, nx = x2 - x1;
+            float wy = 1.f, wx = 1.f;
+            if (y1 > 0 && ly < feather) wy = ramp[ly];
+            if (y2 < H && ly >= ny - feather) wy = ramp[ny - 1 - ly];
+            if (x1 > 0 && lx < feather) wx = ramp[lx];
+            if (x2 < W && lx >= nx - feather) wx = ramp[nx - 1 - lx];
+            const float m2 = wy * wx;
+            for (int c = 0; c < C; ++c) {
+                const float v = tiles[(((long long)t * C + c) * th + ly) * tw + lx] * scale;
+                acc[c] = acc[c] + v * m2;
+            }
+            wsum = wsum + m2;
+        }
+        for (int c = 0; c < C; ++c) {
+            const float q = rintf(acc[c] / wsum);
+            out[i * C + c] = (uint8_t)fminf(fmaxf(q, 0.f), 255.f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dc_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int N, int C, int H, int W, void* stream)
@@ -375,5 +411,16 @@ extern "C" int dc_pack_sixch_u8_f32(const uint8_t* img0_hw3, const uint8_t* img1
     if (!img0_hw3 || !img1_hw3 || !dst_6hw || H <= 0 || W <= 0) return DC_ERR_INVALID;
     hipLaunchKernelGGL(pack_sixch_kernel, dim3(grid_for((long long)H * W)), dim3(256), 0, (hipStream_t)stream, img0_hw3, img1_hw3,
                        dst_6hw, (long long)H * W);
+    return dc_launch_status();
+}
+
+extern "C" int dc_blend_tiles_ramp_u8(const float* tiles_nchw, const int* coords_dev, int T, int C, int th, int tw,
+                                      const float* ramp_dev, int feather, uint8_t* out_hwc, int H, int W, float scale, void* stream)
+{
+    if (!tiles_nchw || !coords_dev || !out_hwc || T <= 0 || C <= 0 || C > 4 || th <= 0 || tw <= 0 || H <= 0 || W <= 0 || feather < 0 ||
+        (feather > 0 && !ramp_dev) || 2 * feather > th || 2 * feather > tw)
+        return DC_ERR_INVALID;
+    hipLaunchKernelGGL(blend_tiles_ramp_kernel, dim3(grid_for((long long)H * W)), dim3(256), 0, (hipStream_t)stream, tiles_nchw,
+                       coords_dev, T, C, th, tw, ramp_dev, feather, out_hwc, H, W, scale);
     return dc_launch_status();
 }

@@ -548,3 +548,22 @@ def pack_sixch(img0_u8, img1_u8):
     out = torch.empty((1, 6, h, w), device=img0_u8.device, dtype=F32)
     lib.call("dc_pack_sixch_u8_f32", img0_u8.data_ptr(), img1_u8.data_ptr(), out.data_ptr(), h, w, _stream())
     return out
+
+
+def blend_tiles_ramp(tiles_nchw, coords, full_hw, feather):
+    """tiles [T,C,th,tw] fp32 in [0,1] on the device, coords [(y1,y2,x1,x2)] full-size windows -> uint8 [H,W,C] (device).
+    Same weights and fp32 op order as tiling.merge_ramp."""
+    import numpy as np
+    _chk(tiles_nchw, F32, "tiles")
+    t, c, th, tw = tiles_nchw.shape
+    h, w = full_hw
+    assert len(coords) == t and all(y2 - y1 == th and x2 - x1 == tw for (y1, y2, x1, x2) in coords)
+    f = int(feather)
+    dev = tiles_nchw.device
+    ramp = (0.5 - 0.5 * np.cos(np.pi * (np.arange(f, dtype=np.float32) + 0.5) / f)).astype(np.float32) if f > 0 else np.zeros(1, np.float32)
+    ramp_d = torch.from_numpy(ramp).to(dev)
+    coords_d = torch.tensor(coords, dtype=torch.int32).reshape(-1, 4).to(dev)
+    out = torch.empty((h, w, c), device=dev, dtype=torch.uint8)
+    lib.call("dc_blend_tiles_ramp_u8", tiles_nchw.data_ptr(), coords_d.data_ptr(), t, c, th, tw, ramp_d.data_ptr(), f,
+             out.data_ptr(), h, w, 255.0, _stream())
+    return out

@@ -31,7 +31,7 @@ def plan_tiles(height, width, tile=512, overlap=64):
 
 @torch.no_grad()
 def decode_tiled(pipe, controlnet_cond, flow_cond, prompt_embeds, negative_prompt_embeds=None, tile=512, overlap=64,
-                 batch=8, latents=None, generator=None, feather=None, **pipe_kwargs):
+                 batch=8, latents=None, generator=None, feather=None, device_blend=True, **pipe_kwargs):
     """controlnet_cond [1,6,H,W], flow_cond [1,4,H,W] (full frame) -> uint8 image [H,W,3].
     `latents` (optional) is the full-frame noise [1,4,H/8,W/8]; each tile takes its window of it, so overlapping regions
     start from identical noise."""
@@ -49,6 +49,12 @@ def decode_tiled(pipe, controlnet_cond, flow_cond, prompt_embeds, negative_promp
         pe = prompt_embeds.expand(len(chunk), -1, -1).contiguous()
         npe = None if negative_prompt_embeds is None else negative_prompt_embeds.expand(len(chunk), -1, -1).contiguous()
         out = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cc, flow_cond=fc, latents=lt,
-                   output_type="np", **pipe_kwargs).images                                   # [n, tile, tile, 3] in [0,1]
-        tiles_out += [np.asarray(o * 255.0, np.float32) for o in out]
-    return tiling.merge_ramp(tiles_out, coords, (h, w), order="hwc", feather=overlap if feather is None else feather), coords
+                   output_type="pt", **pipe_kwargs).images                                   # [n, 3, tile, tile] fp32 in [0,1]
+        tiles_out.append(out.float())
+    tiles_dev = torch.cat(tiles_out, 0).contiguous()
+    f = overlap if feather is None else feather
+    if device_blend and tiles_dev.is_cuda and 2 * f <= tile:
+        from . import ops
+        return ops.blend_tiles_ramp(tiles_dev, coords, (h, w), f).cpu().numpy(), coords        # one gather kernel, uint8 comes back
+    host = [np.asarray(t.permute(1, 2, 0).cpu().numpy() * 255.0, np.float32) for t in tiles_dev]
+    return tiling.merge_ramp(host, coords, (h, w), order="hwc", feather=f), coords

@@ -190,6 +190,14 @@ int dc_flow_hw2_resize_scale_f32(const float* src_hw2, int H, int W, float* dst_
  * (TF.to_tensor's x/255, image 0 in planes 0-2, image 1 in planes 3-5). */
 int dc_pack_sixch_u8_f32(const uint8_t* img0_hw3, const uint8_t* img1_hw3, float* dst_6hw, int H, int W, void* stream);
 
+/* ------------------------------------------------------------------ tiled decode (patch_exp.ipynb / patch_utils.py) */
+/* Blend of full-size decoded tiles into the frame with half-cosine ramps on inner tile edges (this package's
+ * tiled-decode policy, tiling.merge_ramp; the reference's merge_costiles window is kept host-side for parity only).
+ * tiles [T][C][th][tw] fp32 in [0,1]; coords int32 [T][4] = (y1, y2, x1, x2) with y2-y1 == th, x2-x1 == tw;
+ * ramp [feather] fp32; out uint8 [H][W][C] = clip(rint(sum(scale*tile*w) / sum(w))); every pixel must be covered. */
+int dc_blend_tiles_ramp_u8(const float* tiles_nchw, const int* coords_dev, int T, int C, int th, int tw,
+                           const float* ramp_dev, int feather, uint8_t* out_hwc, int H, int W, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,3 +402,21 @@ def test_conv3x3_four_output_channels_on_the_tile_kernel(ops):
     close(out.permute(0, 3, 1, 2).cpu(), ref)
     # the direct small-Cout kernel stays the fallback for shapes the tile kernel does not take
     assert ops.PackedConv(wt[:3], b[:3], DEV, mfma_small_cout=True).kind == "small_cout"
+
+
+@pytest.mark.parametrize("hw,tile,overlap", [((256, 448), 256, 64), ((540, 960), 256, 64), ((512, 512), 512, 64), ((300, 300), 128, 32)])
+def test_blend_tiles_ramp_equals_host_merge(ops, hw, tile, overlap):
+    """Tiled-decode blend kernel vs tiling.merge_ramp (host, numpy fp32) on the windows of plan_tiles: same weights, same
+    fp32 op order -> bit-exact uint8 frame.  Covers 1x2, 3x5 (1080p/2-like), a single window, and a 3x3 plan."""
+    import numpy as np
+    from diffcodec_amd import tiling
+    from diffcodec_amd.tiled_decode import plan_tiles
+    h, w = hw
+    coords = plan_tiles(h, w, tile, overlap)
+    g = torch.Generator().manual_seed(19)
+    tiles = torch.rand(len(coords), 3, tile, tile, generator=g)
+    host = tiling.merge_ramp([np.asarray(t.permute(1, 2, 0).numpy() * 255.0, np.float32) for t in tiles], coords, (h, w),
+                             order="hwc", feather=overlap)
+    dev = ops.blend_tiles_ramp(tiles.to(DEV), coords, (h, w), overlap).cpu().numpy()
+    assert dev.shape == host.shape == (h, w, 3) and dev.dtype == np.uint8
+    assert np.array_equal(dev, host)
