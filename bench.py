@@ -174,6 +174,35 @@ def main():
         single = dict(frames_per_step=1, ms_per_frame=round((time.perf_counter() - t1) / 3 * 1e3, 2))
         single["frames_per_s"] = round(1e3 / single["ms_per_frame"], 3)
 
+    # ---- U-Net forward alone (north_star's target is quoted on it): model batch 2F exactly as inside a denoising step
+    #      (text K/V cached, CFG halves sharing their common prefix, ControlNet residuals added), graph-replayed, after the
+    #      timed region.  FLOPs = the reference's algorithmic work, 803.3 GFLOP per sample-forward.
+    unet_fwd = None
+    if rank == 0 and not args.no_roofline:
+        one_step(0)                                            # leaves contexts / controls / buffers of the F-frame batch in place
+        st = pipe._state
+        ttab = torch.full((STEPS_DDIM,), 500.0, device=device)
+        stepc = torch.zeros(1, device=device, dtype=torch.int32)
+        down, mid = pipe.controlnet.forward_nhwc(st["x_in"], ttab, 1.7, step_dev=stepc, cfg_shared=True)
+        fwd = lambda: pipe.unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=stepc, cfg_shared=True)
+        fwd()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fwd()
+        gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        tf = 0.8033 * 2 * F / (ms * 1e-3)
+        unet_fwd = dict(model_batch=2 * F, ms=round(ms, 3), tflops=round(tf, 1), frac_of_bf16_peak=round(tf / PEAK_BF16_TFLOPS, 4),
+                        note="U-Net forward only, 803.3 GFLOP of reference work per sample (all kernels: GEMM, attention, norms)")
+        del gr, down, mid
+
     # ---- roofline leg (after the timed region): HIP events around every MFMA implicit-GEMM launch of one eager frame
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -239,7 +268,7 @@ def main():
                        "frames_per_step_per_gpu": F, "hip_graphs": not args.no_graphs, "parallelism": f"frame-shard x{world}"},
             "frame_tflop_algorithmic": round(TFLOP_PER_FRAME, 2),
             "frame_mfma_frac": round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
-            "single_frame": single, "roofline": roof, "cpu_baseline": cpu,
+            "single_frame": single, "unet_forward": unet_fwd, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
