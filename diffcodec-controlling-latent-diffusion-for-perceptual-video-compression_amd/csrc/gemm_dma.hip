@@ -12,6 +12,7 @@
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Developer-only phase stamps (tools/gemm_stamp.py builds this file with -DDC_STAMP into a scratch .so): s_memtime at
 // kernel entry / after the first stage landed / after the K loop / at exit, written to the (otherwise unused) split-K
@@ -115,12 +116,16 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     auto issue_stage = [&](int kt, int slot) {
         kt = kt < kt_end ? kt : kt_end - 1;           // past-the-end stages re-read the last one (keeps vmcnt counts constant)
         char* base = smem + slot * STAGE;
+        if (kt < c1_steps) {                          // first K range (the only one without a channel concat): no per-piece select
+#pragma unroll
+            for (int i = 0; i < NGW; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src1[i] + (long long)kt * 128), (lptr_t)(base + ldsoff[i]), 16, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NGW; ++i) {
             const bool is_a = (G0 + wave + 4 * i) * 8 < BM;                    // wave-uniform
-            const char* p;
-            if (is_a && kt >= c1_steps) p = src2[i] + (long long)(kt - c1_steps) * 128;
-            else p = src1[i] + (long long)kt * 128;
+            const char* p = is_a ? src2[i] + (long long)(kt - c1_steps) * 128 : src1[i] + (long long)kt * 128;
             __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + ldsoff[i]), 16, 0, 0);
         }
     };
@@ -293,13 +298,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
         // cooperative store: consecutive lanes -> consecutive 16-byte pieces of one output row
         const int out_cols = d.epilogue == 1 ? d.Cout >> 1 : d.Cout;
         const int col0 = d.epilogue == 1 ? n0 >> 1 : n0;
-        const int pieces = ocols / 8;                           // 16-byte pieces per staged row
         bf16_t* __restrict__ o = (bf16_t*)d.out;
-        for (int i = tid; i < BM * pieces; i += 256) {
-            const int row = i / pieces, pc = i - row * pieces;
-            const int m = m0 + row, c = col0 + pc * 8;
-            if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
-        }
+        auto store_rows = [&](auto pieces_c) {                  // 16-byte pieces per staged row: a compile-time divisor
+            constexpr int pieces = decltype(pieces_c)::value;
+            for (int i = tid; i < BM * pieces; i += 256) {
+                const int row = i / pieces, pc = i - row * pieces;
+                const int m = m0 + row, c = col0 + pc * 8;
+                if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
+            }
+        };
+        if (d.epilogue == 1) store_rows(std::integral_constant<int, OC / 16>{});
+        else store_rows(std::integral_constant<int, OC / 8>{});
         DC_STAMP_AT(3);
         return;
     }
