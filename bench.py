@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--steps-per-graph", type=int, default=1, help="denoising steps captured per hipGraph")
     ap.add_argument("--dual-stream", type=int, default=1, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
@@ -119,7 +120,7 @@ def main():
         nbytes = sharding.broadcast_params(sharding.module_param_tensors(pipe.unet, pipe.controlnet, pipe.vae))
         torch.cuda.synchronize()
         log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s")
-    pipe.enable_hip_graphs(not args.no_graphs)
+    pipe.enable_hip_graphs(not args.no_graphs, steps_per_graph=args.steps_per_graph)
     pipe.enable_dual_stream(bool(args.dual_stream))
 
     F = args.frames

@@ -67,6 +67,7 @@ class StableDiffusionDualFlowControlNetPipeline:
         self._use_graphs = False
         self._dual_stream = False
         self._cfg_shared = True
+        self._graph_chunk = 1
         self._graphs = {}
         self._state = {}
         self.device = getattr(unet, "device", torch.device("cuda"))
@@ -92,8 +93,11 @@ class StableDiffusionDualFlowControlNetPipeline:
         self.unet.disable_freeu()
         self._graphs.clear()
 
-    def enable_hip_graphs(self, flag=True):
+    def enable_hip_graphs(self, flag=True, steps_per_graph=1):
+        """Capture denoising steps as hipGraphs and replay them.  steps_per_graph > 1 puts that many consecutive steps
+        (same control scale) into one graph: fewer graph launches per frame, which matters at one frame per pass."""
         self._use_graphs = bool(flag)
+        self._graph_chunk = max(1, int(steps_per_graph))
 
     def enable_cfg_shared_prefix(self, flag=True):
         """Compute the layers ahead of the first text cross-attention once for both classifier-free-guidance halves
@@ -351,26 +355,37 @@ class StableDiffusionDualFlowControlNetPipeline:
                 eps = unet.decode_nhwc(sample, list(res), temb, down, mid)
             ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
 
-        for i in range(len(sched.timesteps)):
+        nsteps = len(sched.timesteps)
+        scales = [float(base_scale * keep[i]) for i in range(nsteps)]
+        i = 0
+        while i < nsteps:
             if self.interrupt:
-                continue
-            scale = float(base_scale * keep[i])
+                break
+            scale = scales[i]
             if not self._use_graphs:
                 one_step(scale)
+                i += 1
                 continue
-            gkey = (scale, float(guidance), shared, self._dual_stream)
+            if i == 0 and not st.get("warm"):
+                one_step(scale)                               # eager warm-up (lazy kernel attributes) before any capture
+                st["warm"] = True
+                i += 1
+                continue
+            # several consecutive steps with the same control scale replay as ONE graph (the step counter lives on the device)
+            chunk = 1
+            while chunk < self._graph_chunk and i + chunk < nsteps and scales[i + chunk] == scale:
+                chunk += 1
+            gkey = (scale, float(guidance), shared, self._dual_stream, chunk)
             g = self._graphs.get(gkey)
             if g is None:
-                if i == 0 and not st.get("warm"):
-                    one_step(scale)                           # eager warm-up (lazy kernel attributes) before any capture
-                    st["warm"] = True
-                    continue
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the RCCL watchdog thread of a multi-rank job polls events while we capture; in the default
                 # global mode that invalidates the capture
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    one_step(scale)
-                self._graphs[gkey] = g                        # capture does not execute: replay below runs step i
+                    for _ in range(chunk):
+                        one_step(scale)
+                self._graphs[gkey] = g                        # capture does not execute: replay below runs the steps
             g.replay()
+            i += chunk
         return st["lat"].clone()

@@ -393,3 +393,22 @@ def test_control_guidance_window_vs_oracle(small):
     finally:
         pipe.enable_hip_graphs(False)
     assert T.psnr(img_h, img) > 45.0
+
+
+def test_multi_step_graphs_equal_single_step_graphs(small):
+    """`enable_hip_graphs(steps_per_graph=k)`: k consecutive steps in one captured graph (the step counter lives on the
+    device) give the same frame as one graph per step, incl. a remainder chunk (5 steps = 3 + 2) and a control-guidance
+    window that splits chunks at the scale change."""
+    T, pipe, _ = small
+    cond, flow, pe, npe, lat = _inputs(T)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=5, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+    for extra in ({}, dict(control_guidance_end=0.6)):
+        base = pipe(**kw, **extra).images.float().cpu()
+        try:
+            pipe.enable_hip_graphs(True, steps_per_graph=3)
+            a = pipe(**kw, **extra).images.float().cpu()
+            b = pipe(**kw, **extra).images.float().cpu()          # second call: pure replay
+        finally:
+            pipe.enable_hip_graphs(False)
+        assert T.psnr(a, base) > 45.0 and T.psnr(b, base) > 45.0
