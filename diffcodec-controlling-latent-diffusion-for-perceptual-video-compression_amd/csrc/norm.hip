@@ -104,8 +104,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // Small maps (<= 16x16): the whole statistic in ONE launch, one workgroup per (sample, group), reading that group's
 // channels of cat[x1, x2] directly (bf16 pairs; a pixel's group slice is contiguous).  Measured (tools/bench_gn.py):
 // 4-8 us against 8-15 us for the slab + finalize pair at 8x8 / 16x16; slower from 32x32 up (strided reads, few
-// workgroups), where the pair stays.  An atomics + last-workgroup-finalises variant was tried and dropped (fp32 atomics:
-// 24-105 us at 32 samples).
+// workgroups), where the pair stays.  One-launch variants that finalise in the last workgroup to arrive were tried twice
+// and dropped: with fp32 atomics on the sums (24-105 us at 32 samples) and with plain slabs + one ticket atomic per
+// workgroup (48-178 us) — the agent-scope `__threadfence()` the hand-off needs (L2 write-back + invalidate across the
+// eight XCDs) costs far more than the dependent launch it saves.
 __global__ __launch_bounds__(256) void gn_direct_kernel(const bf16_t* __restrict__ x1, int C1, const bf16_t* __restrict__ x2,
                                                         int C2, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ ab, long long HW, int groups, int tp, float inv_count,
