@@ -147,7 +147,7 @@ class HipDualFlowControlNet:
         ab = ops.group_norm_ab(sample, None, None, self.cfg["groups"], 1e-5)
         return ops.fdn_modulate(sample, ab, gamma, beta)
 
-    def forward_nhwc(self, x, t_dev, conditioning_scale=1.0, step_dev=None, cfg_shared=False):
+    def forward_nhwc(self, x, t_dev, conditioning_scale=1.0, step_dev=None, cfg_shared=False, features_only=False):
         """x NHWC bf16 [n,h,w,4] -> (12 residuals, mid) NHWC bf16.  Needs set_context + prepare_controls first."""
         enc = self.enc
         temb = enc.temb(t_dev, x.shape[0], step_dev)
@@ -159,6 +159,10 @@ class HipDualFlowControlNet:
 
         sample, res = enc.run_down(sample, temb, after_block=hook, cfg_shared=cfg_shared)
         sample = enc.run_mid(sample, temb)                                  # :112-118
+        if features_only:
+            # the caller applies the zero-convs itself with the UNet skip as the GEMM's residual operand
+            # (HipUNet2DConditionModel.decode_nhwc(control=...)): zero_conv(f) * scale + skip in one epilogue
+            return res, sample
         down = [ops.conv(r, z, out_scale=conditioning_scale) for r, z in zip(res, self.zero)]   # :120-128
         mid = ops.conv(sample, self.zero_mid, out_scale=conditioning_scale)
         return down, mid

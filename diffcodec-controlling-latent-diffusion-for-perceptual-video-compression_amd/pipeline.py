@@ -337,8 +337,9 @@ class StableDiffusionDualFlowControlNetPipeline:
                 # every residual by 0, so adding them changes nothing — skip the ControlNet for this step
                 eps = unet.forward_nhwc(st["x_in"], ttab, None, None, step_dev=st["step"], cfg_shared=shared)
             elif not self._dual_stream:
-                down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared)
-                eps = unet.forward_nhwc(st["x_in"], ttab, down, mid, step_dev=st["step"], cfg_shared=shared)
+                feats, midf = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared, features_only=True)
+                eps = unet.forward_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared,
+                                        control=(feats, midf, cn.zero, cn.zero_mid, scale))
             else:
                 # The ControlNet and the UNet's down path are independent until the skip additions (flownet.py:83-124 vs
                 # pipeline.py:358-367): two HIP streams, joined before the UNet mid block.  Every tensor crossing streams
@@ -347,12 +348,12 @@ class StableDiffusionDualFlowControlNetPipeline:
                 side = st.setdefault("side_stream", torch.cuda.Stream(device=device))
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    down, mid = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared)
+                    feats, midf = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared, features_only=True)
                 sample, res, temb = unet.encode_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared)
                 main.wait_stream(side)
-                for t_ in down + [mid]:
+                for t_ in feats + [midf]:
                     t_.record_stream(main)
-                eps = unet.decode_nhwc(sample, list(res), temb, down, mid)
+                eps = unet.decode_nhwc(sample, list(res), temb, control=(feats, midf, cn.zero, cn.zero_mid, scale))
             ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
 
         nsteps = len(sched.timesteps)

@@ -96,13 +96,23 @@ class HipUNet2DConditionModel:
         sample, res = enc.run_down(sample, temb, cfg_shared=cfg_shared)
         return sample, res, temb
 
-    def decode_nhwc(self, sample, res, temb, down_res=None, mid_res=None):
+    def decode_nhwc(self, sample, res, temb, down_res=None, mid_res=None, control=None):
+        """control = (features[12], mid_feature, zero_convs[12], zero_mid, scale) from
+        `HipDualFlowControlNet.forward_nhwc(features_only=True)`: the ControlNet's zero-convs (flownet.py:120-128) run here
+        with the skip tensor as the GEMM's residual operand — zero_conv(f) * scale + skip in one epilogue instead of a
+        conv and a separate add (pipeline.py:364-365)."""
         enc = self.enc
-        if down_res is not None:
+        if control is not None:
+            feats, mid_feat, zero, zero_mid, scale = control
+            assert down_res is None and mid_res is None and len(feats) == len(res) == len(zero)
+            res = [ops.conv(f, z, out_scale=scale, residual=r) for f, z, r in zip(feats, zero, res)]
+        elif down_res is not None:
             assert len(down_res) == len(res)
             res = [ops.add_bf16(a, b) for a, b in zip(res, down_res)]          # pipeline.py:364 residual injection
         sample = enc.run_mid(sample, temb)
-        if mid_res is not None:
+        if control is not None:
+            sample = ops.conv(mid_feat, zero_mid, out_scale=scale, residual=sample)
+        elif mid_res is not None:
             sample = ops.add_bf16(sample, mid_res)
         for bi, blk in enumerate(self.up):
             for r, a in zip(blk["resnets"], blk["attns"]):
@@ -118,11 +128,11 @@ class HipUNet2DConditionModel:
         ab = ops.group_norm_ab(sample, self.norm_out[0], self.norm_out[1], self.cfg["groups"], 1e-5)
         return ops.conv(sample, self.conv_out, gn_ab=ab, gn_silu=True, out_f32=True)
 
-    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None, cfg_shared=False):
+    def forward_nhwc(self, x, t_dev, down_res=None, mid_res=None, step_dev=None, cfg_shared=False, control=None):
         """x NHWC bf16 [n,h,w,4]; t_dev fp32 device scalar (or table indexed by step_dev); residuals NHWC bf16.
         cfg_shared: the caller guarantees x[:n/2] == x[n/2:] (see TransformerBlock).  Returns eps NHWC fp32 [n,h,w,4]."""
         sample, res, temb = self.encode_nhwc(x, t_dev, step_dev, cfg_shared)
-        return self.decode_nhwc(sample, list(res), temb, down_res, mid_res)
+        return self.decode_nhwc(sample, list(res), temb, down_res, mid_res, control)
 
     def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, return_dict=False, **kw):
