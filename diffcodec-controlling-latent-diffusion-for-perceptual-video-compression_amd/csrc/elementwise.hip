@@ -101,12 +101,12 @@ __global__ void latents_to_model_input_kernel(const float* __restrict__ lat, bf1
     }
 }
 __global__ void postprocess_kernel(const float* __restrict__ x, float* __restrict__ o32, uint8_t* __restrict__ o8, int C,
-                                   long long HW, long long total)
+                                   long long HW, long long total, int xs)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C);
         const long long p = (i / C) % HW, n = i / (C * HW);
-        float v = x[i] / 2.0f + 0.5f;
+        float v = x[(i / C) * xs + c] / 2.0f + 0.5f;             // xs: input elements per pixel (>= C when the conv padded Cout)
         v = fminf(fmaxf(v, 0.f), 1.f);
         if (o32) o32[(n * C + c) * HW + p] = v;
         if (o8) o8[i] = (uint8_t)rintf(v * 255.0f);
@@ -387,11 +387,14 @@ extern "C" int dc_latents_to_model_input(const float* latents, void* model_in, f
                        latents, (bf16_t*)model_in, mul, rep, B, C, (long long)H * W);
     return dc_launch_status();
 }
-extern "C" int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W, void* stream)
+extern "C" int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W,
+                                    int x_pixel_stride, void* stream)
 {
+    if (x_pixel_stride == 0) x_pixel_stride = C;
+    if (x_pixel_stride < C) return DC_ERR_INVALID;
     if (!x || (!out_nchw_f32 && !out_nhwc_u8)) return DC_ERR_INVALID;
     const long long total = (long long)N * C * H * W;
-    hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out_nchw_f32, out_nhwc_u8, C, (long long)H * W, total);
+    hipLaunchKernelGGL(postprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out_nchw_f32, out_nhwc_u8, C, (long long)H * W, total, x_pixel_stride);
     return dc_launch_status();
 }
 

@@ -518,11 +518,14 @@ def latents_to_model_input(latents, mul=1.0, rep=1, out=None):
 
 
 def postprocess_image(x_nhwc_f32, want_u8=False):
-    _chk(x_nhwc_f32, F32, "x")
-    n, h, w, c = x_nhwc_f32.shape
-    o32 = torch.empty((n, c, h, w), device=x_nhwc_f32.device, dtype=F32)
-    o8 = torch.empty((n, h, w, c), device=x_nhwc_f32.device, dtype=torch.uint8) if want_u8 else None
-    lib.call("dc_postprocess_image", x_nhwc_f32.data_ptr(), o32.data_ptr(), _ptr(o8), n, c, h, w, _stream())
+    """x [n,h,w,c] fp32; may be a channel-slice view of a wider contiguous tensor (conv_out run with a padded channel)."""
+    x = x_nhwc_f32
+    n, h, w, c = x.shape
+    if not (x.is_cuda and x.dtype == F32 and x.stride(3) == 1 and x.stride(1) == w * x.stride(2) and x.stride(0) == h * x.stride(1)):
+        raise ValueError("x: expected a device fp32 NHWC tensor or a channel-slice view of one")
+    o32 = torch.empty((n, c, h, w), device=x.device, dtype=F32)
+    o8 = torch.empty((n, h, w, c), device=x.device, dtype=torch.uint8) if want_u8 else None
+    lib.call("dc_postprocess_image", x.data_ptr(), o32.data_ptr(), _ptr(o8), n, c, h, w, int(x.stride(2)), _stream())
     return o32, o8
 
 

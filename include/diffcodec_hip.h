@@ -180,7 +180,8 @@ int dc_cfg_ddim_step(const float* eps, float* latents, void* model_in, const flo
 /* latents NCHW f32 [B,C,H,W] * mul -> NHWC bf16 [rep*B,H,W,C] (pipeline.py:313-320, :391 scaling) */
 int dc_latents_to_model_input(const float* latents, void* model_in, float mul, int rep, int B, int C, int H, int W, void* stream);
 /* image_processor.postprocess — pipeline.py:397-398: (x/2+0.5).clamp(0,1); x NHWC f32 [N,H,W,3] -> NCHW f32 and/or NHWC u8 */
-int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W, void* stream);
+int dc_postprocess_image(const float* x, float* out_nchw_f32, uint8_t* out_nhwc_u8, int N, int C, int H, int W,
+                         int x_pixel_stride /* input elements per pixel, 0 = C (4 when conv_out ran with a padded 4th channel) */, void* stream);
 
 /* ------------------------------------------------------------------ input side (controlnet/utils.py) */
 /* resize_flow_to (utils.py:21-28) on the .flo payload layout: src [H][W][2] fp32 (pixel units) -> dst [2][th][tw] fp32,

@@ -412,3 +412,31 @@ def test_multi_step_graphs_equal_single_step_graphs(small):
         finally:
             pipe.enable_hip_graphs(False)
         assert T.psnr(a, base) > 45.0 and T.psnr(b, base) > 45.0
+
+
+def test_full_size_sd15_vae_decode_and_postprocess():
+    """True SD-1.5 VAE widths (128/256/512/512) on a 16x16 latent (128x128 image): decode vs the fp32 oracle.  At these
+    widths conv_out (128 -> 3) runs on the MFMA tile kernel with a zero 4th channel, and the image reaches
+    `dc_postprocess_image` as a channel-slice view (pixel stride 4)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import ops, selftest as T, weights as W
+    from diffcodec_amd.unet import to_nhwc_bf16
+    from diffcodec_amd.vae import HipAutoencoderKL
+    from oracle import sd15_ref as M
+    cfg = W.SD15_VAE_CONFIG
+    vsd = W.synthesize(W.vae_spec(), 2)
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = M.vae_decode(vsd, cfg, z)
+    vae = HipAutoencoderKL(vsd, cfg, DEV)
+    assert vae.d_conv_out.kind == "igemm" and vae.d_conv_out.cout == 4
+    img = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert tuple(img.shape) == (2, 3, 128, 128)
+    assert T.rel_l2(img.float().cpu(), ref) < 4e-2
+    nhwc = vae.decode_nhwc(to_nhwc_bf16(z.to(DEV)))
+    assert nhwc.shape == (2, 128, 128, 3) and nhwc.stride(2) == 4
+    o32, o8 = ops.postprocess_image(nhwc, want_u8=True)
+    want = (nhwc.permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1)
+    assert torch.equal(o32, want.contiguous())
+    assert torch.equal(o8, (want.permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8))
