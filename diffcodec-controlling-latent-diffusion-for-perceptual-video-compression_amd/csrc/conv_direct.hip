@@ -76,6 +76,63 @@ __global__ __launch_bounds__(256) void conv3x3_nchw_f32_kernel(const float* __re
     }
 }
 
+// conv_in of the UNet / ControlNet (4 -> 320, 3x3, stride 1, pad 1): thread = (4 consecutive output pixels of a row, group of
+// 8 output channels).  Each of the 36 weight vectors is loaded once and used for four pixels, the 3 x 6 input pixels of
+// the strip are 8-byte loads: 4x fewer weight loads per FMA than the generic kernel below (197 -> ~80 us at 32 x 64 x 64).
+__global__ __launch_bounds__(256) void conv_in4_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                       const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                       int N, int H, int W, int Cout)
+{
+    const int cog = Cout >> 3, wq = W >> 2;
+    const long long total = (long long)N * H * wq * cog;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int g = (int)(i % cog);
+    const long long s = i / cog;
+    const int ox0 = (int)(s % wq) * 4, oy = (int)((s / wq) % H), n = (int)(s / ((long long)wq * H));
+    float acc[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        float xin[6][4];                                   // input pixels ox0-1 .. ox0+4 of this row, 4 channels each
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int ix = ox0 + q - 1;
+            bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (ix >= 0 && ix < W) v = *(const bf16x4*)(x + (((long long)n * H + iy) * W + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xin[q][c] = (float)v[c];
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bf16x8 wv = *(const bf16x8*)(w + ((long long)((ky * 3 + kx) * 4 + c)) * Cout + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float wf = (float)wv[j];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[p][j] += xin[p + kx][c] * wf;
+                }
+            }
+    }
+    float b8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b8[j] = bias ? bias[g * 8 + j] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(acc[p][j] + b8[j]);
+        *(bf16x8*)(out + ((((long long)n * H + oy) * W) + ox0 + p) * Cout + g * 8) = o;
+    }
+}
+
 // thread = (pixel, group of 8 output channels); w [taps][Cin][Cout] bf16
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -200,6 +257,12 @@ extern "C" int dc_conv_small_cin_bf16(const void* x, const void* w, const float*
                                       int Cin, int Cout, int ksize, int stride, int pad, int Ho, int Wo, void* stream)
 {
     if (!x || !w || !out || N <= 0 || Cin <= 0 || Cin > 16 || Cout <= 0 || (ksize != 1 && ksize != 3)) return DC_ERR_INVALID;
+    if (Cin == 4 && ksize == 3 && stride == 1 && pad == 1 && (Cout & 7) == 0 && (W & 3) == 0 && Ho == H && Wo == W) {
+        const long long strips = (long long)N * H * (W >> 2) * (Cout >> 3);
+        hipLaunchKernelGGL(conv_in4_kernel, dim3(dc_cdiv(strips, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)w, bias, (bf16_t*)out, N, H, W, Cout);
+        return dc_launch_status();
+    }
     const long long total = (long long)N * Ho * Wo * ((Cout + 7) / 8);
     hipLaunchKernelGGL(conv_small_cin_kernel, dim3(dc_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (const bf16_t*)w, bias, (bf16_t*)out, N, H, W, Cin, Cout, ksize, stride, pad, Ho, Wo);

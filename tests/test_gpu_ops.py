@@ -204,6 +204,12 @@ def test_small_channel_convs(ops):
     b = torch.randn(64, generator=g) * 0.1
     out = ops.conv(nhwc(x), ops.PackedConv(w, b, DEV))
     close(from_nhwc(out), F.conv2d(x, w, b, padding=1))
+    # conv_in 4 -> 320 at 64x64 (4-pixel-strip kernel), without bias, and a width that is not a multiple of 4 (generic kernel)
+    xin = bf(torch.randn(3, 4, 64, 64, generator=g))
+    win = bf(torch.randn(320, 4, 3, 3, generator=g) / 6)
+    close(from_nhwc(ops.conv(nhwc(xin), ops.PackedConv(win, None, DEV))), F.conv2d(xin, win, None, padding=1))
+    xw = bf(torch.randn(1, 4, 10, 18, generator=g))
+    close(from_nhwc(ops.conv(nhwc(xw), ops.PackedConv(w, b, DEV))), F.conv2d(xw, w, b, padding=1))
     x3 = bf(torch.randn(1, 3, 20, 12, generator=g))
     w3 = bf(torch.randn(32, 3, 3, 3, generator=g) / 5)
     close(from_nhwc(ops.conv(nhwc(x3), ops.PackedConv(w3, None, DEV))), F.conv2d(x3, w3, None, padding=1))
