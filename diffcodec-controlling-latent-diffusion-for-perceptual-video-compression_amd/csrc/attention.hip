@@ -38,7 +38,11 @@ struct AttnArgs {
 // at 1 wave/SIMD it parks accumulators in AGPRs and pays ~180 v_accvgpr moves per K/V tile in the softmax.
 // QB = 32-query blocks per wave: with QB = 2 every K fragment and every transposed V read feeds two MFMAs, and the
 // staging / barrier cost per key tile is shared by 256 queries per workgroup instead of 128.
-template <int D, int QB>
+// SHORT (Nk <= 2 * KV_TILE, i.e. the 77-token text context of every cross-attention): both key tiles are staged once
+// and stay in the two LDS buffers while the workgroup walks over SHORT_PASSES query blocks — no barrier, no K/V traffic
+// and no staging latency per block; the long form pays all three once per 128*QB queries for two iterations of work.
+constexpr int SHORT_PASSES = 4;
+template <int D, int QB, bool SHORT>
 __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
 {
     constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     constexpr int VT_BYTES = KV_TILE * V_PITCH;
     constexpr int BUF = K_BYTES + VT_BYTES;
     constexpr int QW = 32 * QB;                      // queries per wave
+    constexpr int OPITCH = D * 2 + 16;               // staged output row pitch (SHORT): 16-byte aligned rows, off a power of two
     static_assert(NDT <= 5, "head dim <= 160");
     // Row sums for free: when the head dim leaves a spare zero-padded column (d = 40, 80, 8, 16), V's column D is set to
     // 1.0 in LDS, so O^T row D accumulates sum_k p — the softmax denominator — inside the PV MFMA, already rescaled by
@@ -63,11 +68,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int qblocks = (a.Nq + 4 * QW - 1) / (4 * QW);
+    constexpr int QWG = 4 * QW * (SHORT ? SHORT_PASSES : 1);   // queries per workgroup
+    const int qblocks = (a.Nq + QWG - 1) / QWG;
     const int bh = blockIdx.x / qblocks;
     const int qb = blockIdx.x - bh * qblocks;
     const int b = bh / a.heads, h = bh - b * a.heads;
-    const int q0 = qb * 4 * QW + wave * QW;
+    int q0 = qb * QWG + wave * QW;
 
     const bf16_t* __restrict__ Q = a.q + (long long)b * a.Nq * a.qs + h * D;
     const bf16_t* __restrict__ K = a.k + (long long)b * a.Nk * a.ks + h * D;
@@ -83,30 +89,33 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     // Q^T fragments: lane holds Q[q0 + 32*u + lq][16*ks + 8*lh .. +7]
     bf16x8 qf[QB][ND16];
-#pragma unroll
-    for (int u = 0; u < QB; ++u)
-#pragma unroll
-        for (int ks = 0; ks < ND16; ++ks) {
-            const int dcol = 16 * ks + 8 * lh;
-            const int qi = q0 + 32 * u + lq;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (qi < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)qi * a.qs + dcol);
-            qf[u][ks] = *(bf16x8*)&v;
-        }
-
     f32x16 oacc[QB][NDT];
-#pragma unroll
-    for (int u = 0; u < QB; ++u)
-#pragma unroll
-        for (int t = 0; t < NDT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[u][t][r] = 0.f;
     float m_run[QB], l_run[QB];
+    auto fetch_q = [&](int qbase, bf16x8 (&dst)[QB][ND16]) {   // Q^T fragments of the block at qbase
 #pragma unroll
-    for (int u = 0; u < QB; ++u) {
-        m_run[u] = -INFINITY;
-        l_run[u] = 0.f;
-    }
+        for (int u = 0; u < QB; ++u)
+#pragma unroll
+            for (int ks = 0; ks < ND16; ++ks) {
+                const int dcol = 16 * ks + 8 * lh;
+                const int qi = qbase + 32 * u + lq;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (qi < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)qi * a.qs + dcol);
+                dst[u][ks] = *(bf16x8*)&v;
+            }
+    };
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[u][t][r] = 0.f;
+            m_run[u] = -INFINITY;
+            l_run[u] = 0.f;
+        }
+    };
+    fetch_q(q0, qf);
+    reset_acc();
 
     u32x4 rk[NLD], rv[NLD];
     const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
@@ -146,10 +155,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     __syncthreads();
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    for (int t = 0; t < ntiles; ++t) {
+    auto process_tile = [&](int t) {
         const int buf = t & 1;
-        const bool more = t + 1 < ntiles;
-        if (more) issue_loads(t + 1);
         const char* sK = smem + buf * BUF;
         const char* sV = sK + K_BYTES;
         const int kb = t * KV_TILE;
@@ -238,11 +245,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                         oacc[u][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[u][j][s2], oacc[u][tt], 0, 0, 0);
                 }
         }
-        if (more) store_lds(buf ^ 1);
-        __syncthreads();
-    }
+    };
 
     // ---- finish: O[q][d] = O^T[d][q] / l
+    auto store_out = [&]() {
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
         float l_tot;
@@ -250,7 +256,23 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         else l_tot = l_run[u] + __shfl_xor(l_run[u], 32, 64);
         const float inv = 1.0f / l_tot;
         const int qi = q0 + 32 * u + lq;
-        if (qi < a.Nq) {
+        if constexpr (SHORT) {
+            // rows staged in this wave's LDS slice, then written as whole 16-byte pieces of contiguous rows: a per-lane
+            // 8-byte store at a row stride touches 32 lines per instruction, and the short form lives on its stores
+            char* stg = smem + 2 * BUF + wave * (QW * OPITCH) + (32 * u + lq) * OPITCH;
+#pragma unroll
+            for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int dcol = 32 * tt + 8 * g + 4 * lh;
+                    if (dcol < D) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(oacc[u][tt][4 * g + r] * inv);
+                        *(bf16x4*)(stg + dcol * 2) = pk;
+                    }
+                }
+        } else if (qi < a.Nq) {
             bf16_t* __restrict__ O = a.o + ((long long)b * a.Nq + qi) * a.os + h * D;
 #pragma unroll
             for (int tt = 0; tt < NDT; ++tt)
@@ -266,22 +288,69 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 }
         }
     }
+    if constexpr (SHORT) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // this wave's staged rows are visible to all of its lanes
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const char* stw = smem + 2 * BUF + wave * (QW * OPITCH);
+        for (int i = lane; i < QW * NV; i += 64) {                // NV = 16-byte pieces per row
+            const int row = i / NV, pc = i - row * NV;
+            const int qi = q0 + row;
+            if (qi < a.Nq)
+                *(u32x4*)(a.o + ((long long)b * a.Nq + qi) * a.os + h * D + pc * 8) = *(const u32x4*)(stw + row * OPITCH + pc * 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // reads done before the next pass overwrites the slice
+        __builtin_amdgcn_wave_barrier();
+    }
+    };
+
+    if constexpr (!SHORT) {
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = t + 1 < ntiles;
+            if (more) issue_loads(t + 1);
+            process_tile(t);
+            if (more) store_lds((t & 1) ^ 1);
+            __syncthreads();
+        }
+        store_out();
+    } else {
+        if (ntiles > 1) {                                      // second key tile: staged once, like the first
+            issue_loads(1);
+            store_lds(1);
+            __syncthreads();
+        }
+        for (int pass = 0;; ++pass) {                          // K/V stay put: the waves run on independently, block after block
+            const bool has_next = pass + 1 < SHORT_PASSES && q0 + 4 * QW < a.Nq;
+            bf16x8 qn[QB][ND16];
+            if (has_next) fetch_q(q0 + 4 * QW, qn);            // next block's queries fly while this one computes
+            for (int t = 0; t < ntiles; ++t) process_tile(t);
+            store_out();
+            if (!has_next) break;
+            q0 += 4 * QW;
+#pragma unroll
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int ks = 0; ks < ND16; ++ks) qf[u][ks] = qn[u][ks];
+            reset_acc();
+        }
+    }
 }
 
-template <int D, int QB>
+template <int D, int QB, bool SHORT>
 int launch_qb(const AttnArgs& a, hipStream_t st)
 {
     constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
     constexpr int KP16 = (ND16 * 2) | 1;
     constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
-    const size_t lds = 2 * BUF;
-    auto kern = attn_kernel<D, QB>;
+    const size_t lds = 2 * BUF + (SHORT ? 4 * (32 * QB) * (D * 2 + 16) : 0);
+    auto kern = attn_kernel<D, QB, SHORT>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int qblocks = (a.Nq + 128 * QB - 1) / (128 * QB);
+    constexpr int QWG = 128 * QB * (SHORT ? SHORT_PASSES : 1);
+    const int qblocks = (a.Nq + QWG - 1) / QWG;
     hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);
     return dc_launch_status();
 }
@@ -291,11 +360,19 @@ int launch(const AttnArgs& a, hipStream_t st)
 {
     // two query blocks per wave only for the small heads (register budget) and only when that still leaves >= 2 workgroups per CU
     static const int force_qb = getenv("DC_ATTN_QB") ? atoi(getenv("DC_ATTN_QB")) : 0;      // developer knob
+    static const int no_short = getenv("DC_ATTN_NO_SHORT") ? atoi(getenv("DC_ATTN_NO_SHORT")) : 0;   // developer knob (A/B)
+    // short context (text cross-attention): keys resident, several query blocks per workgroup — when enough workgroups remain
+    const bool short_ctx = !no_short && a.Nk <= 2 * KV_TILE;
     if constexpr (D <= 48) {          // d = 80 spills at two blocks per wave (measured slower)
         const long long wgs2 = (long long)a.B * a.heads * ((a.Nq + 255) / 256);
-        if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) return launch_qb<D, 2>(a, st);
+        if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) {
+            if (short_ctx && wgs2 / SHORT_PASSES >= 512) return launch_qb<D, 2, true>(a, st);
+            return launch_qb<D, 2, false>(a, st);
+        }
     }
-    return launch_qb<D, 1>(a, st);
+    const long long wgs1 = (long long)a.B * a.heads * ((a.Nq + 127) / 128);
+    if (short_ctx && wgs1 / SHORT_PASSES >= 512) return launch_qb<D, 1, true>(a, st);
+    return launch_qb<D, 1, false>(a, st);
 }
 
 // Row softmax fp32 -> bf16 (one workgroup per row; cols <= 65536).

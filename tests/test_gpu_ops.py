@@ -281,7 +281,9 @@ def test_layer_norm(ops):
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("b,heads,nq,nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
                                              (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),
-                                             (1, 2, 33, 5, 8), (1, 3, 200, 200, 32), (1, 1, 128, 192, 128)])
+                                             (1, 2, 33, 5, 8), (1, 3, 200, 200, 32), (1, 1, 128, 192, 128),
+                                             # text cross-attention at full batch: keys resident, 4 query blocks per workgroup
+                                             (16, 8, 4096, 77, 40), (32, 8, 1000, 77, 80), (40, 8, 250, 100, 160)])
 def test_attention(ops, b, heads, nq, nk, d):
     g = torch.Generator().manual_seed(11)
     c = heads * d
