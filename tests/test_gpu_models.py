@@ -442,3 +442,39 @@ def test_full_size_sd15_vae_decode_and_postprocess():
     want = (nhwc.permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1)
     assert torch.equal(o32, want.contiguous())
     assert torch.equal(o8, (want.permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8))
+
+
+def test_full_size_20_step_decode_vs_oracle():
+    """BASELINE configs[1] end to end: one 512x512 frame, 20-step DDIM, CFG 4.5, control scale 1.7, true SD-1.5 widths,
+    through the fused loop (hipGraphs, two streams, shared CFG prefix) against the fp32 CPU oracle on identical seeded
+    weights and inputs.  Measured 47.8 dB / latent rel-L2 0.011 (tools/full_decode_parity.py); the oracle takes ~40 s."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    from diffcodec_amd import selftest as T, weights as W
+    from diffcodec_amd.controlnet import HipDualFlowControlNet
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline
+    from diffcodec_amd.scheduler import DDIMScheduler
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    from diffcodec_amd.unet import HipUNet2DConditionModel
+    from diffcodec_amd.vae import HipAutoencoderKL
+    from oracle import pipeline_ref as R
+    usd, csd, vsd = W.synthesize(W.unet_spec(), 0), W.synthesize(W.controlnet_spec(), 1), W.synthesize(W.vae_spec(), 2)
+    cond, flow = synth_controls(1, 512)
+    pe, npe = synth_text(1)
+    lat = synth_latents(1, 512)
+    kw = dict(num_inference_steps=20, guidance_scale=4.5, controlnet_conditioning_scale=1.7)
+    pipe = StableDiffusionDualFlowControlNetPipeline(vae=HipAutoencoderKL(vsd), text_encoder=None, tokenizer=None,
+                                                     unet=HipUNet2DConditionModel(usd), controlnet=HipDualFlowControlNet(csd),
+                                                     scheduler=DDIMScheduler(), safety_checker=None, feature_extractor=None)
+    pipe.enable_hip_graphs(True)
+    pipe.enable_dual_stream(True)
+    call = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, **kw)
+    img = pipe(output_type="pt", **call).images.float().cpu()
+    lat_d = pipe(output_type="latent", **call).images.float().cpu()
+    ref_img, ref_lat = R.decode_frame(usd, csd, vsd, W.SD15_UNET_CONFIG, W.SD15_VAE_CONFIG, cond, flow, pe, npe, lat,
+                                      return_latents=True, **kw)
+    assert img.shape == ref_img.shape == (1, 3, 512, 512)
+    assert T.rel_l2(lat_d, ref_lat) < 4e-2
+    assert T.psnr(img, ref_img) > 35.0
