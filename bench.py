@@ -56,38 +56,30 @@ def build_pipeline(rank, device):
     return pipe, (sds if rank == 0 else None)
 
 
-def cpu_baseline(sds, threads):
-    """Oracle (CPU restatement, kind 'port') on the host cores, bounded sample of the same workload:
-    ONE DDIM step with CFG (ControlNet + UNet at model batch 2, 512x512) + the control pyramid + VAE decode,
-    extrapolated to 20 steps.  Reported next to the GPU number; never part of `value`."""
-    from diffcodec_amd import weights as W
+def cpu_baseline(sds, threads, device_decode=None):
+    """Oracle (CPU restatement, kind 'port') on the host cores: ONE whole 512x512 frame through the fp32 loop (pyramid +
+    20 DDIM steps with CFG at model batch 2 + VAE decode), timed as it is — no extrapolation.  The same frame decoded by
+    the device pipeline gives the PSNR of the metric's "vs ref" half.  Reported next to the GPU number; never part of `value`."""
+    from diffcodec_amd import selftest as T, weights as W
     from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
-    from oracle import control_ref as C
-    from oracle import sd15_ref as M
+    from oracle import pipeline_ref as R
     torch.set_num_threads(threads)
     usd, csd, vsd = sds
     cond, flow = synth_controls(1, SIZE)
     pe, npe = synth_text(1)
     lat = synth_latents(1, SIZE)
-    ctx = torch.cat([npe, pe], 0)
-    x = torch.cat([lat, lat], 0)
-    with torch.no_grad():
-        t0 = time.time()
-        pyr = C.bi_dir_feature_extractor(csd, "feature_extractor.", cond, flow)
-        t_pyr = time.time() - t0
-        t0 = time.time()
-        p2 = [torch.cat([q, q], 0) for q in pyr]
-        down, mid = M.dualflow_controlnet_forward(csd, W.SD15_UNET_CONFIG, x, 951, ctx, None, None, 1.7, pyramid=p2)
-        eps = M.unet_forward(usd, W.SD15_UNET_CONFIG, x, 951, ctx, down, mid)
-        t_step = time.time() - t0
-        t0 = time.time()
-        M.vae_decode(vsd, W.SD15_VAE_CONFIG, lat / 0.18215)
-        t_vae = time.time() - t0
-    assert torch.isfinite(eps).all()
-    frame_s = t_pyr + STEPS_DDIM * t_step + t_vae
-    return dict(value=1.0 / frame_s, unit="frames/s", cores=threads, kind="port",
-                sample=f"1 of 20 DDIM steps (CFG, ControlNet+UNet, batch 2) {t_step:.2f}s + pyramid {t_pyr:.2f}s + VAE decode "
-                       f"{t_vae:.2f}s at 512x512 fp32, extrapolated x20 steps -> {frame_s:.1f}s/frame")
+    kw = dict(num_inference_steps=STEPS_DDIM, guidance_scale=4.5, controlnet_conditioning_scale=1.7)
+    t0 = time.time()
+    ref = R.decode_frame(usd, csd, vsd, W.SD15_UNET_CONFIG, W.SD15_VAE_CONFIG, cond, flow, pe, npe, lat, **kw)
+    frame_s = time.time() - t0
+    assert torch.isfinite(ref).all()
+    out = dict(value=1.0 / frame_s, unit="frames/s", cores=threads, kind="port",
+               sample=f"one whole frame: pyramid + 20 DDIM steps (CFG, ControlNet+UNet, batch 2) + VAE decode at 512x512 fp32, "
+                      f"{frame_s:.1f}s measured (not extrapolated)")
+    if device_decode is not None:
+        img = device_decode(dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat), kw)
+        out["psnr_db_device_vs_cpu"] = round(T.psnr(img.float().cpu(), ref), 2)
+    return out
 
 
 def main():
@@ -254,7 +246,9 @@ def main():
                          "(each distinct launch shape timed back-to-back x10 on the launch stream, weighted by its count)")
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sds, threads=max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("DC_CPU_THREADS", "16")))))
+        dev_decode = lambda inp, kw_: pipe(**{k: v.to(device) for k, v in inp.items()}, output_type="pt", **kw_).images
+        cpu = cpu_baseline(sds, threads=max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("DC_CPU_THREADS", "16")))),
+                           device_decode=dev_decode)
 
     if rank == 0:
         frames = F * world * args.steps
