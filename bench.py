@@ -245,7 +245,7 @@ def main():
                     note="sum of algorithmic 2*M*N*K over the igemm launches of one frame / sum of their HIP-event launch durations "
                          "(each distinct launch shape timed back-to-back x10 on the launch stream, weighted by its count)")
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # host-core baseline: single-GPU runs only
         dev_decode = lambda inp, kw_: pipe(**{k: v.to(device) for k, v in inp.items()}, output_type="pt", **kw_).images
         cpu = cpu_baseline(sds, threads=max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("DC_CPU_THREADS", "16")))),
                            device_decode=dev_decode)
