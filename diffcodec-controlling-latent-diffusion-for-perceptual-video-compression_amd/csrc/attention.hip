@@ -344,11 +344,8 @@ int launch_qb(const AttnArgs& a, hipStream_t st)
     constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
     const size_t lds = 2 * BUF + (SHORT ? 4 * (32 * QB) * (D * 2 + 16) : 0);
     auto kern = attn_kernel<D, QB, SHORT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
     constexpr int QWG = 128 * QB * (SHORT ? SHORT_PASSES : 1);
     const int qblocks = (a.Nq + QWG - 1) / QWG;
     hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);

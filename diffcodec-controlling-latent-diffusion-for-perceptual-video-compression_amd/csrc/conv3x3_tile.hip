@@ -224,14 +224,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     for (int cc = c_begin; cc < c_end; ++cc) {
         const bool more_c = cc + 1 < c_end;
         for (int tap = 0; tap < 9; ++tap, ++step) {
-            wait_vmcnt<NB * (NSTB - 2)>();                       // this wave's pieces of weight stage `step` have landed
-            __builtin_amdgcn_s_barrier();                        // everyone's have; halo image visible; slot step-1 is free
+            dc_ring_sync<NB * (NSTB - 2)>();                     // this wave's pieces of weight stage `step` have landed and its reads of
+                                                                 // step-1 have returned; after the barrier everyone's have: halo image
+                                                                 // visible, slot step-1 free
             if (tap == 0 && more_c) issue_halo(cc + 1);          // lands under the next eight K-steps
             issue_b(step + NSTB - 1, (step + NSTB - 1) % NSTB);
             compute(tap, step % NSTB);
         }
         if (more_c) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the halo image have returned
             __builtin_amdgcn_s_barrier();                        // every wave is past its last read of the halo image
+            asm volatile("" ::: "memory");
             store_halo(cc + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible after the next K-step's barrier
         }
@@ -316,11 +320,8 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
 #define DC_TILE_LAUNCH(GN)                                                                                      \
     do {                                                                                                        \
         auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB>;                                                          \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
+        static std::atomic<unsigned long long> attr_done{0};                                                    \
+        dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
     } while (0)
     if (d.gn_ab) DC_TILE_LAUNCH(true);

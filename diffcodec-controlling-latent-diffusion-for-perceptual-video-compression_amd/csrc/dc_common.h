@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define DC_OK 0
 #define DC_ERR_INVALID (-1)
@@ -54,9 +55,38 @@ __device__ __forceinline__ float dc_wave_max(float v)
     return v;
 }
 
+// One K-step hand-over of an LDS ring filled by LDS-DMA: wait until all but the N youngest vector-memory operations of
+// this wave have landed AND until every LDS read this wave has issued has returned, then the workgroup barrier.
+// The lgkmcnt(0) is what makes the ring safe to refill: hipcc software-pipelines the last fragment reads of a K-step past
+// a raw s_barrier (the MFMAs that consume them are register-only, so nothing orders them against it), and a wave that
+// arrives at the barrier with reads still in flight lets another wave's DMA refill the stage under them — rare wrong
+// tiles that differ from run to run (found with tools/find_nondeterminism.py on the unrolled TM=2 tile conv).  The
+// sched_barrier keeps the step's MFMAs in front of the wait (so the wait is normally already satisfied), the compiler
+// barrier after s_barrier keeps the next step's LDS reads behind it.
+template <int N>
+__device__ __forceinline__ void dc_ring_sync()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 static inline int dc_launch_status()
 {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DC_OK : DC_ERR_LAUNCH;
+}
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): one bit per device ordinal in a per-kernel mask.  The only
+// process-wide state of the library; lock-free (setting the attribute twice is harmless, so two host threads racing on the
+// first launch merely repeat the call) and correct when one process drives several devices.
+static inline void dc_set_max_dyn_lds(const void* kern, int bytes, std::atomic<unsigned long long>& done)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
 }
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

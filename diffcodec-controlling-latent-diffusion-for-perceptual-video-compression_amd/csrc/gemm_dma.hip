@@ -209,16 +209,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             }
             compute(k & 1);
             if (more) store_a((k + 1) & 1);
-            wait_vmcnt<0>();                                    // this wave's weight pieces of stage k+1 have landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and its A rows are written
-            __builtin_amdgcn_s_barrier();
+            dc_ring_sync<0>();                                  // this wave's weight pieces of stage k+1 have landed, its A rows are
+                                                                // written and its reads of stage k have returned
         }
     } else {
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s) issue_stage(kt_begin + s, s);
         for (int k = 0; k < nk; ++k) {
-            wait_vmcnt<NGW * (NST - 2)>();                // this wave's pieces of stage k have landed
-            __builtin_amdgcn_s_barrier();                 // ... and everyone else's; everyone is also done reading stage k-1
+            dc_ring_sync<NGW * (NST - 2)>();              // this wave's pieces of stage k have landed and its reads of stage k-1 have
+                                                          // returned; after the barrier: everyone else's too
             if (k == 0) DC_STAMP_AT(1);
             issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
             compute(k % NST);
@@ -382,11 +381,8 @@ int launch_gemm(const dc_conv_desc& d, hipStream_t st)
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
     const size_t lds = (size_t)NST * (BM + BN) * 128;
     auto kern = gemm_dma_kernel<TM, TN, NST, A_REG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);
     return dc_launch_status();
 }

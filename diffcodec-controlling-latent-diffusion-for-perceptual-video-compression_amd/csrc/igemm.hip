@@ -343,11 +343,8 @@ int launch_cfg(const dc_conv_desc& d, hipStream_t st)
 #define DC_IGEMM_LAUNCH(KS3, GN)                                                                              \
     do {                                                                                                      \
         auto kern = igemm_kernel<WM, WN, TM, TN, KS3, GN>;                                                    \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) {                                                                                      \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                  \
-        }                                                                                                     \
+        static std::atomic<unsigned long long> attr_done{0};                                                  \
+        dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                           \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                \
     } while (0)
     if (d.ksize == 3) {

@@ -101,12 +101,9 @@ extern "C" int dc_attention_causal_small_bf16(const void* q, const void* k, cons
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || T <= 0 || T > TMAX || D <= 0 || D > DMAX) return DC_ERR_INVALID;
     const size_t lds = sizeof(float) * ((size_t)T * (D + 1) + (size_t)T * D + 4 * D + 4 * T);
     auto kern = attn_causal_small_kernel;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(float) * ((size_t)TMAX * (DMAX + 1) + (size_t)TMAX * DMAX + 4 * DMAX + 4 * TMAX)));
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    dc_set_max_dyn_lds((const void*)kern, (int)(sizeof(float) * ((size_t)TMAX * (DMAX + 1) + (size_t)TMAX * DMAX + 4 * DMAX + 4 * TMAX)),
+                       attr_done);
     hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (bf16_t*)out, heads, T, D, q_stride, k_stride, v_stride, out_stride, scale);
     return dc_launch_status();

@@ -229,7 +229,7 @@ class StableDiffusionDualFlowControlNetPipeline:
         cond_base_scale = controlnet_conditioning_scale[0] if isinstance(controlnet_conditioning_scale, list) else float(controlnet_conditioning_scale)
 
         fused = (isinstance(self.unet, HipUNet2DConditionModel) and isinstance(self.controlnet, HipDualFlowControlNet)
-                 and isinstance(self.scheduler, DDIMScheduler) and callback_on_step_end is None and not guess_mode and not eta)
+                 and isinstance(self.scheduler, DDIMScheduler) and callback_on_step_end is None and not guess_mode and not eta)   # eta > 0: generic loop
         if fused:
             latents = self._denoise_fused(latents, prompt_embeds, negative_prompt_embeds, controlnet_cond, flow_cond, do_cfg,
                                           guidance_scale, cond_base_scale, controlnet_keep)

@@ -57,9 +57,21 @@ class DDIMScheduler:
             rows.append([(1 - a_t) ** 0.5, a_t ** 0.5, a_p ** 0.5, (1 - a_p) ** 0.5])
         return torch.tensor(rows, dtype=torch.float32)
 
+    @staticmethod
+    def _same_device(a, b):
+        """torch.device('cuda') != torch.device('cuda:0') although both name the current device: compare the type and
+        the index with `None` resolved to the current device."""
+        a, b = torch.device(a), torch.device(b)
+        if a.type != b.type:
+            return False
+        if a.type != "cuda":
+            return True
+        cur = torch.cuda.current_device() if (a.index is None or b.index is None) else 0
+        return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
     def device_tables(self, device):
         """(coef [steps,4] fp32, timesteps [steps] fp32) resident on the device for graph-replayed steps."""
-        if self._coef_dev is None or self._coef_dev[0].device != torch.device(device):
+        if self._coef_dev is None or not self._same_device(self._coef_dev[0].device, device):
             self._coef_dev = (self.coefficients().to(device), self.timesteps.float().to(device))
             # captured hipGraphs hold raw pointers into these tables: consumers key on this counter, never on id() of the
             # tensors (a freed table's id can be handed to its successor)
@@ -67,13 +79,30 @@ class DDIMScheduler:
         return self._coef_dev
 
     def step(self, model_output, timestep, sample, eta=0.0, generator=None, return_dict=True, **kw):
-        """Generic (non-fused) entry: model_output/sample logical NCHW device tensors.  eta must be 0."""
-        if eta:
-            raise NotImplementedError("eta > 0 (stochastic DDIM) is not implemented")
+        """Generic (non-fused) entry: model_output/sample logical NCHW device tensors.
+        eta > 0 (pipeline.py:289 forwards it through prepare_extra_step_kwargs) is diffusers' stochastic DDIM [recalled]:
+        sigma_t = eta * sqrt((1-a_prev)/(1-a_t)) * sqrt(1 - a_t/a_prev); x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev-sigma_t^2) eps
+        + sigma_t * noise, the noise drawn with the caller's generator on the generator's device (CPU generator -> CPU draw,
+        then moved: `randn_tensor`).  One `dc_lincomb4_f32` launch on fp32 state."""
         idx = (self.timesteps == int(timestep)).nonzero()
         if idx.numel() == 0:
             raise ValueError(f"timestep {timestep} is not in the current schedule")
         dev = sample.device
+        if eta:
+            t = int(timestep)
+            prev = t - self.num_train_timesteps // self.num_inference_steps
+            a_t = float(self.alphas_cumprod[t])
+            a_p = float(self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
+            var = (1.0 - a_p) / (1.0 - a_t) * (1.0 - a_t / a_p)
+            std = float(eta) * var ** 0.5
+            gdev = generator.device if isinstance(generator, torch.Generator) else dev
+            noise = torch.randn(tuple(model_output.shape), generator=generator, device=gdev, dtype=torch.float32).to(dev)
+            x = sample.float().contiguous()
+            eps = model_output.float().contiguous()
+            c_x = (a_p / a_t) ** 0.5
+            c_eps = -(a_p * (1.0 - a_t) / a_t) ** 0.5 + (1.0 - a_p - std * std) ** 0.5
+            lat = ops.lincomb([(c_x, x), (c_eps, eps), (std, noise.contiguous())])
+            return (lat,) if not return_dict else type("DDIMOut", (), {"prev_sample": lat})()
         coef, _ = self.device_tables(dev)
         step = torch.tensor([int(idx[0])], dtype=torch.int32, device=dev)
         lat = sample.float().contiguous().clone()

@@ -53,6 +53,7 @@ class HipAutoencoderKL:
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = torch.bfloat16
+        state_dict = weights.remap_vae_attention_keys(state_dict)      # legacy query/key/value/proj_attn names
         self.config = SimpleNamespace(scaling_factor=cfg["scaling_factor"], block_out_channels=list(cfg["block_out_channels"]),
                                       latent_channels=cfg["latent_channels"])
         sd, g, boc = state_dict, cfg["groups"], cfg["block_out_channels"]

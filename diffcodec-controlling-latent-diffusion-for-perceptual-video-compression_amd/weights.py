@@ -342,12 +342,33 @@ def load_safetensors(path):
     return load_file(path)
 
 
+_VAE_ATTN_LEGACY = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def remap_vae_attention_keys(sd):
+    """SD-1.5's `vae/diffusion_pytorch_model.safetensors` predates diffusers' Attention refactor: its mid-block attention
+    is stored as `*.attentions.0.{query,key,value,proj_attn}.{weight,bias}` (some exports as [C,C,1,1] 1x1-conv weights)
+    and diffusers renames them while loading (`AutoencoderKL.from_pretrained`, validation.py:33) [recalled].  Same
+    conversion here: -> `{to_q,to_k,to_v,to_out.0}` with [C,C] weights.  New-style checkpoints pass through unchanged."""
+    out = OrderedDict()
+    for k, v in sd.items():
+        parts = k.split(".")
+        if len(parts) >= 3 and "attentions" in parts and parts[-2] in _VAE_ATTN_LEGACY:
+            k = ".".join(parts[:-2] + [_VAE_ATTN_LEGACY[parts[-2]], parts[-1]])
+        if ".attentions." in k and k.endswith(".weight") and v.dim() == 4 and v.shape[2:] == (1, 1) and \
+                k.rsplit(".", 2)[-2] in ("to_q", "to_k", "to_v", "0"):
+            v = v[:, :, 0, 0]
+        out[k] = v
+    return out
+
+
 def load_diffusers_subfolder(base, sub):
     """<base>/<sub>/{config.json, diffusion_pytorch_model.safetensors} (validation.py:33-34)."""
     d = os.path.join(base, sub)
     with open(os.path.join(d, "config.json")) as f:
         cfg = json.load(f)
-    return cfg, load_safetensors(os.path.join(d, "diffusion_pytorch_model.safetensors"))
+    sd = load_safetensors(os.path.join(d, "diffusion_pytorch_model.safetensors"))
+    return cfg, (remap_vae_attention_keys(sd) if sub == "vae" else sd)
 
 
 def filter_state_dict(ckpt, spec):

@@ -3,7 +3,8 @@
  *
  * One shared object (libdiffcodec_hip.so) of `extern "C"` launchers.  Every entry point:
  *   - takes plain device pointers + sizes (no torch / C++ types), the HIP stream as `void*`;
- *   - allocates nothing and keeps no global state (workspaces are passed in);
+ *   - allocates nothing (workspaces are passed in); the only process-wide state is one lock-free bit per
+ *     (kernel, device) recording that the kernel's dynamic-LDS limit was raised on that device;
  *   - enqueues on the given stream and returns immediately: 0 = ok, -1 = invalid argument,
  *     -2 = launch failure.  Safe to capture into a hipGraph.
  *

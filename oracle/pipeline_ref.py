@@ -30,13 +30,19 @@ class DDIMRef:
     def scale_model_input(self, x, t):
         return x
 
-    def step(self, eps, t, x):
+    def step(self, eps, t, x, eta=0.0, noise=None):
+        """eta > 0: diffusers' stochastic DDIM [recalled] in its own (unfolded) form — variance of `_get_variance`,
+        direction term sqrt(1 - a_prev - std^2) eps, plus std * noise."""
         t = int(t)
         prev = t - self.T // self.n
         a_t = self.alphas_cumprod[t]
         a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
-        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+        if not eta:
+            return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+        var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+        std = eta * var ** 0.5
+        return a_p ** 0.5 * x0 + (1 - a_p - std ** 2) ** 0.5 * eps + std * noise
 
 
 class UniPCRef:
@@ -130,7 +136,7 @@ class UniPCRef:
 def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flow_cond, prompt_embeds,
                  negative_prompt_embeds, latents, num_inference_steps=20, guidance_scale=7.5,
                  controlnet_conditioning_scale=1.0, output_type="pt", hoist=True, return_latents=False,
-                 control_guidance_start=0.0, control_guidance_end=1.0):
+                 control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None):
     """pipeline.py:144-404, `prompt_embeds=` path.  hoist=True computes the step-invariant pyramid once
     (identical values to recomputing it every step as the reference does, flownet.py:78)."""
     do_cfg = guidance_scale is not None and guidance_scale > 1.0            # pipeline.py:202
@@ -153,7 +159,8 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
         if do_cfg:
             eu, et = eps.chunk(2)
             eps = eu + guidance_scale * (et - eu)                           # :370-372
-        latents = sched.step(eps, t, latents)                               # :375
+        noise = torch.randn(tuple(eps.shape), generator=generator, dtype=torch.float32) if eta else None   # :289 -> step(eta=, generator=)
+        latents = sched.step(eps, t, latents, eta, noise)                   # :375
     if output_type == "latent" or return_latents and vae_sd is None:
         return latents
     img = M.vae_decode(vae_sd, vae_cfg, latents / vae_cfg["scaling_factor"])   # :391

@@ -93,3 +93,63 @@ def test_pipeline_validation_errors_need_no_gpu():
              controlnet_cond=torch.zeros(2, 6, 64, 64), flow_cond=torch.zeros(2, 4, 64, 64))
     with pytest.raises(ValueError, match="divisible by 8"):
         pipe(prompt_embeds=pe, negative_prompt_embeds=pe, controlnet_cond=torch.zeros(1, 6, 60, 60), flow_cond=torch.zeros(1, 4, 60, 60))
+
+
+def test_device_tables_are_stable_for_equivalent_device_spellings():
+    """torch.device('cuda') != torch.device('cuda:0') made every call rebuild the tables (and drop the captured
+    hipGraphs).  The comparison resolves an index-less CUDA device to the current one; on CPU the same logic is exercised
+    with the spellings 'cpu' / torch.device('cpu')."""
+    s = DDIMScheduler()
+    s.set_timesteps(20)
+    a = s.device_tables("cpu")
+    v = s.table_version
+    b = s.device_tables(torch.device("cpu"))
+    assert a[0] is b[0] and a[1] is b[1] and s.table_version == v
+    s.set_timesteps(20)                                  # same schedule: tables kept
+    assert s.device_tables("cpu")[0] is a[0] and s.table_version == v
+    s.set_timesteps(10)                                  # new schedule: rebuilt, version bumped
+    assert s.device_tables("cpu")[0] is not a[0] and s.table_version == v + 1
+    same = DDIMScheduler._same_device
+    assert same("cpu", torch.device("cpu")) and not same("cpu", "meta")
+    assert same(torch.device("cuda", 1), "cuda:1") and not same("cuda:0", "cuda:1")      # explicit indices never touch the runtime
+
+
+def test_vae_legacy_attention_keys_are_remapped():
+    """SD-1.5's vae safetensors stores the mid-block attention as query/key/value/proj_attn (some exports as 1x1-conv
+    weights); diffusers converts on load (validation.py:33).  Same conversion in `remap_vae_attention_keys`."""
+    cfg = dict(W.SD15_VAE_CONFIG, block_out_channels=(32, 64, 64, 64))
+    sd = W.synthesize(W.vae_spec(cfg), 0)
+    legacy = {}
+    names = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    for k, v in sd.items():
+        for new, old in names.items():
+            if f".attentions.0.{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+                if v.dim() == 2 and old != "proj_attn":
+                    v = v[:, :, None, None]              # conv-style export of the linear weight
+                break
+        legacy[k] = v
+    assert sum("query" in k for k in legacy) == 4 and not any(".to_q." in k for k in legacy)
+    back = W.remap_vae_attention_keys(legacy)
+    assert list(back) == list(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    again = W.remap_vae_attention_keys(sd)               # new-style checkpoints pass through
+    assert all(again[k] is sd[k] for k in sd)
+    kept, rep = W.filter_state_dict(back, W.vae_spec(cfg))
+    assert not rep["missing"] and not rep["mismatched"] and not rep["unexpected"]
+
+
+def test_ddim_eta_matches_oracle_on_cpu_tensors():
+    """eta > 0 (pipeline.py:289): the folded coefficients of `DDIMScheduler.step` equal the oracle's unfolded form."""
+    from oracle.pipeline_ref import DDIMRef
+    s, r = DDIMScheduler(), DDIMRef()
+    s.set_timesteps(10)
+    r.set_timesteps(10)
+    x, e, nz = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    ratio = s.num_train_timesteps // s.num_inference_steps
+    for t in s.timesteps.tolist():
+        prev = t - ratio
+        a_t = float(s.alphas_cumprod[t])
+        a_p = float(s.alphas_cumprod[prev] if prev >= 0 else s.final_alpha_cumprod)
+        std = 0.7 * ((1 - a_p) / (1 - a_t) * (1 - a_t / a_p)) ** 0.5
+        mine = (a_p / a_t) ** 0.5 * x + (-(a_p * (1 - a_t) / a_t) ** 0.5 + (1 - a_p - std * std) ** 0.5) * e + std * nz
+        torch.testing.assert_close(mine, r.step(e, t, x, 0.7, nz), rtol=1e-5, atol=1e-5)
