@@ -15,6 +15,9 @@ from .ops import PackedConv
 # measured (profiles/r01_igemm_shapes_frames16.txt): the GN-on-load 1x1 igemm runs at ~250-350 TFLOP/s, the DMA GEMM at
 # 400-750; the extra elementwise pass only pays for itself below this many rows
 PROJ_IN_FUSE_MIN_ROWS = int(os.environ.get("DC_PROJ_IN_FUSE_MIN_ROWS", "65536"))
+# LayerNorm folded into the following linear's weights + epilogue (ops.PackedConv(ln=...)): removes the three standalone
+# LayerNorm passes of every BasicTransformerBlock.  DC_LN_FOLD=0 keeps the separate dc_layernorm_bf16 launches (A/B).
+LN_FOLD = os.environ.get("DC_LN_FOLD", "1") != "0"
 
 
 def _f32(sd, key, device):
@@ -91,12 +94,17 @@ class TransformerBlock:
         self.proj_out = PackedConv(sd[p + "proj_out.weight"], sd[p + "proj_out.bias"], device)
         q = p + "transformer_blocks.0."
         self.ln = [(_f32(sd, q + f"norm{i}.weight", device), _f32(sd, q + f"norm{i}.bias", device)) for i in (1, 2, 3)]
-        self.qkv1 = PackedConv(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), None, device)
+        self.fold = LN_FOLD
+
+        def ln(i):                           # nn.LayerNorm(eps=1e-5) parameters folded into the consumer's weights
+            return (sd[q + f"norm{i}.weight"], sd[q + f"norm{i}.bias"], 1e-5) if self.fold else None
+
+        self.qkv1 = PackedConv(torch.cat([sd[q + "attn1.to_q.weight"], sd[q + "attn1.to_k.weight"], sd[q + "attn1.to_v.weight"]], 0), None, device, ln=ln(1))
         self.out1 = PackedConv(sd[q + "attn1.to_out.0.weight"], sd[q + "attn1.to_out.0.bias"], device)
-        self.q2 = PackedConv(sd[q + "attn2.to_q.weight"], None, device)
+        self.q2 = PackedConv(sd[q + "attn2.to_q.weight"], None, device, ln=ln(2))
         self.kv2 = PackedConv(torch.cat([sd[q + "attn2.to_k.weight"], sd[q + "attn2.to_v.weight"]], 0), None, device)
         self.out2 = PackedConv(sd[q + "attn2.to_out.0.weight"], sd[q + "attn2.to_out.0.bias"], device)
-        self.ff1 = PackedConv(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], device, geglu=True)
+        self.ff1 = PackedConv(sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"], device, geglu=True, ln=ln(3))
         self.ff2 = PackedConv(sd[q + "ff.net.2.weight"], sd[q + "ff.net.2.bias"], device)
         self.c = self.proj_in.cout
         self.kv_ctx = None
@@ -115,35 +123,44 @@ class TransformerBlock:
         is then the same for both halves and is computed once; the halves separate at attn2's K/V (the contexts
         [uncond | cond] of `set_context`).  Returns the full [2B] batch.  Same values as running the duplicated batch."""
         n, h, w, c = x.shape
+        fold = self.fold
+        parts = ops.row_stats_parts(c) if fold else 0
+
+        def stats_buf(rows):                 # row statistics (sum, sum of squares) written by the producing GEMM's epilogue
+            return torch.empty((rows, parts, 2), device=x.device, dtype=torch.float32) if fold else None
+
         ab = ops.group_norm_ab(x, self.norm[0], self.norm[1], self.groups, 1e-6)
         if n * h * w > PROJ_IN_FUSE_MIN_ROWS:                    # big maps: GroupNorm applied inside the GEMM's load stage
             t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
+            st = ops.row_stats(t) if fold else None              # that kernel has no statistics epilogue: one read-only pass
         else:                                                    # small maps: a separate pass + the LDS-DMA GEMM is faster
-            t = ops.conv(ops.gn_apply(x, ab), self.proj_in).reshape(n, h * w, c)
-        # self-attention
-        y = ops.layer_norm(t, *self.ln[0])
-        qkv = ops.linear(y, self.qkv1)
+            st = stats_buf(n * h * w)
+            t = ops.conv(ops.gn_apply(x, ab), self.proj_in, stats_out=st).reshape(n, h * w, c)
+        # self-attention (norm1 folded into to_q/k/v)
+        qkv = ops.linear(t, self.qkv1, ln_stats=ops.ln_finalize(st, c, 1e-5)) if fold else ops.linear(ops.layer_norm(t, *self.ln[0]), self.qkv1)
         a = ops.attention(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], self.heads)
-        t = ops.linear(a, self.out1, residual=t)
-        # cross-attention
-        y = ops.layer_norm(t, *self.ln[1])
-        q = ops.linear(y, self.q2)
+        st = stats_buf(n * h * w)
+        t = ops.linear(a, self.out1, residual=t, stats_out=st)
+        # cross-attention (norm2 folded into to_q)
+        q = ops.linear(t, self.q2, ln_stats=ops.ln_finalize(st, c, 1e-5)) if fold else ops.linear(ops.layer_norm(t, *self.ln[1]), self.q2)
         kv = self.kv_ctx
         if not cfg_shared:
             a = ops.attention(q, kv[..., :c], kv[..., c:], self.heads)
-            t = ops.linear(a, self.out2, residual=t)
+            st = stats_buf(n * h * w)
+            t = ops.linear(a, self.out2, residual=t, stats_out=st)
         else:
             assert kv.shape[0] == 2 * n, "cfg_shared needs the [uncond | cond] context batch"
             a = torch.empty((2 * n, h * w, c), device=x.device, dtype=x.dtype)
             t2 = torch.empty_like(a)
+            st = stats_buf(2 * n * h * w)
             for half in (0, 1):                                  # same queries and residual, that half's text keys/values
                 sl = slice(half * n, (half + 1) * n)
                 ops.attention(q, kv[sl, :, :c], kv[sl, :, c:], self.heads, out=a[sl])
-                ops.linear(a[sl], self.out2, residual=t, out=t2[sl])
+                ops.linear(a[sl], self.out2, residual=t, out=t2[sl],
+                           stats_out=st[half * n * h * w:(half + 1) * n * h * w] if fold else None)
             t = t2
-        # GEGLU feed-forward
-        y = ops.layer_norm(t, *self.ln[2])
-        f = ops.linear(y, self.ff1)
+        # GEGLU feed-forward (norm3 folded into ff.net.0.proj)
+        f = ops.linear(t, self.ff1, ln_stats=ops.ln_finalize(st, c, 1e-5)) if fold else ops.linear(ops.layer_norm(t, *self.ln[2]), self.ff1)
         t = ops.linear(f, self.ff2, residual=t)
         if not cfg_shared:
             return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x)

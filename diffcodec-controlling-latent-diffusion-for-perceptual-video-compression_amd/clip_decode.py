@@ -1,0 +1,229 @@
+"""GOP / tile decode driver: a clip -> decode units -> shard over ranks -> batched decode -> (optional) gather + blend.
+
+What it mirrors in the reference: the per-frame harness of validation.py:85-146 (for every inter frame: its two intra
+anchors + its forward / backward flow file -> `load_controls_and_flows` -> `pipe(...)`), the intra/inter split of
+uvc_codec_eval.py:19-26 (`get_inter_frames`: every gop_size-th frame is intra) and the data layout both read:
+
+    <root>/<video>/images/frame_%04d.png
+    <root>/<video>/optical_flow/optical_flow_gop_<G>_raft/flow_<prev>_<cur>.flo        (forward:  prev anchor -> frame)
+    <root>/<video>/optical_flow_bwd/optical_flow_gop_<G>_raft/flow_<next>_<cur>.flo    (backward: next anchor -> frame)
+
+BASELINE configs 3-5 are this driver with different parameters:
+    C3  GOP-12, 512x512, unit = inter frame, units round-robin over 8 ranks;
+    C4  GOP-4, 960x512 as two 512x512 windows per frame, pipe built with [DualFlowControlNet, ResControlNet] + warp_cond;
+    C5  GOP-12, 1080p tiled, 50 steps, unit = (frame, tile) sharded per tile (`shard="tile"`).
+
+Units are independent: there is NO data-path collective.  The only collective here is the optional
+gather of decoded units onto one rank (`gather=True`), needed when the tiles of one frame were decoded on different ranks
+and must be blended.  Trailing-frame policy: an inter frame needs a closing anchor, so frames after the last intra frame
+are not decodable bidirectionally; `sharding.gop_inter_frames` drops them (the reference's `get_inter_frames` merely
+counts them for metrics).  `trailing_frames()` reports which frames were dropped."""
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import sharding
+from .tiled_decode import plan_tiles
+
+
+@dataclass(frozen=True)
+class DecodeUnit:
+    uid: int                 # position in the clip's unit list (what `shard_units` deals)
+    frame: int               # inter frame index
+    prev: int                # previous intra anchor
+    next: int                # next intra anchor
+    window: Tuple[int, int, int, int]   # (y1, y2, x1, x2) in frame pixels; the whole frame when it is one tile
+    tile: int                # index of the window within its frame
+
+
+def plan_units(num_frames, gop_size, height, width, tile=512, overlap=64) -> List[DecodeUnit]:
+    """All decode units of a clip, frame-major: inter frames (uvc_codec_eval.py:19-26) x full-size windows (tiled_decode)."""
+    wins = [(0, height, 0, width)] if (height, width) == (tile, tile) else plan_tiles(height, width, tile, overlap)
+    units = []
+    for f, p, n in sharding.gop_inter_frames(num_frames, gop_size):
+        for ti, w in enumerate(wins):
+            units.append(DecodeUnit(len(units), f, p, n, tuple(w), ti))
+    return units
+
+
+def trailing_frames(num_frames, gop_size):
+    """Inter frames without a closing anchor (dropped; see module docstring)."""
+    last_intra = ((num_frames - 1) // gop_size) * gop_size
+    return [f for f in range(last_intra + 1, num_frames)]
+
+
+def shard(units, rank, world, mode="unit"):
+    """mode 'unit': round-robin over units (C3, C5 per-patch shard); 'frame': all windows of a frame on one rank, frames
+    round-robin (blend without a gather)."""
+    if mode == "unit":
+        return [units[i] for i in sharding.shard_units(len(units), rank, world)]
+    if mode != "frame":
+        raise ValueError("mode must be 'unit' or 'frame'")
+    frames = sorted({u.frame for u in units})
+    mine = {frames[i] for i in sharding.shard_units(len(frames), rank, world)}
+    return [u for u in units if u.frame in mine]
+
+
+class DirectorySource:
+    """Controls of one inter frame from the reference's on-disk layout (validation.py:85-93)."""
+
+    def __init__(self, root, video, gop_size, size, device="cuda", flow_dir="optical_flow", flow_bwd_dir="optical_flow_bwd"):
+        self.root, self.video, self.gop, self.size, self.device = root, video, gop_size, tuple(size), device
+        self.flow_dir, self.flow_bwd_dir = flow_dir, flow_bwd_dir
+
+    def paths(self, frame, prev, nxt):
+        base = os.path.join(self.root, self.video)
+        sub = f"optical_flow_gop_{self.gop}_raft"
+        return (os.path.join(base, "images", f"frame_{prev:04d}.png"), os.path.join(base, "images", f"frame_{nxt:04d}.png"),
+                os.path.join(base, self.flow_dir, sub, f"flow_{prev:04d}_{frame:04d}.flo"),
+                os.path.join(base, self.flow_bwd_dir, sub, f"flow_{nxt:04d}_{frame:04d}.flo"))
+
+    def controls(self, frame, prev, nxt):
+        from .io_utils import load_controls_and_flows
+        return load_controls_and_flows(*self.paths(frame, prev, nxt), size=self.size, device=self.device)
+
+
+class SyntheticSource:
+    """Seeded synthetic controls of the shapes the reference feeds `pipe(...)`; frame f of every rank
+    sees the same tensors, so sharded and unsharded decodes of a clip are comparable."""
+
+    def __init__(self, height, width, device="cuda", seed=1234, with_warp=False):
+        self.h, self.w, self.device, self.seed, self.with_warp = height, width, device, seed, with_warp
+
+    def controls(self, frame, prev, nxt):
+        from .synthetic import synth_controls
+        s = max(self.h, self.w)
+        cond, flow = synth_controls(1, s, seed=self.seed + 7919 * frame)
+        return cond[:, :, :self.h, :self.w].contiguous().to(self.device), flow[:, :, :self.h, :self.w].contiguous().to(self.device)
+
+    def warp(self, frame):
+        g = torch.Generator().manual_seed(self.seed + 104729 * frame + 1)
+        return torch.rand(1, 3, self.h, self.w, generator=g).to(self.device)
+
+
+def frame_noise(frame, height, width, seed, channels=4):
+    """Initial latents of a frame [1,4,H/8,W/8]: a CPU generator seeded per frame (pipeline.py:269-278 draws on the
+    generator's device), so the result does not depend on which rank / batch decodes the frame."""
+    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(frame))
+    return torch.randn((1, channels, height // 8, width // 8), generator=g)
+
+
+@torch.no_grad()
+def decode_units(pipe, units, source, prompt_embeds, negative_prompt_embeds=None, *, batch=16, seed=0, frame_size=None,
+                 output="pt", **pipe_kwargs):
+    """Decode `units` (this rank's share) `batch` at a time.  Returns fp32 [len(units), 3, th, tw] in [0,1] on the device
+    (output='pt') or the latents (output='latent').  Controls of a frame are loaded once and cropped per window; flows keep
+    frame units (patch_exp.ipynb does not re-base them)."""
+    if not units:
+        return torch.empty((0,), device=pipe.device)
+    cache = {}
+
+    def frame_inputs(u):
+        if u.frame not in cache:
+            cache.clear()                                # units are frame-major: one frame's controls live at a time
+            cond, flow = source.controls(u.frame, u.prev, u.next)
+            h, w = (cond.shape[-2], cond.shape[-1]) if frame_size is None else frame_size
+            warp = source.warp(u.frame) if getattr(source, "with_warp", False) else None
+            cache[u.frame] = (cond, flow, frame_noise(u.frame, h, w, seed), warp)
+        return cache[u.frame]
+
+    outs = []
+    for i in range(0, len(units), batch):
+        chunk = units[i:i + batch]
+        cc, fc, lt, wc = [], [], [], []
+        for u in chunk:
+            cond, flow, noise, warp = frame_inputs(u)
+            y1, y2, x1, x2 = u.window
+            cc.append(cond[:, :, y1:y2, x1:x2])
+            fc.append(flow[:, :, y1:y2, x1:x2])
+            lt.append(noise[:, :, y1 // 8:y2 // 8, x1 // 8:x2 // 8])
+            if warp is not None:
+                wc.append(warp[:, :, y1:y2, x1:x2])
+        n = len(chunk)
+        pe = prompt_embeds.expand(n, -1, -1).contiguous() if prompt_embeds.shape[0] == 1 else prompt_embeds[:n]
+        npe = None if negative_prompt_embeds is None else (
+            negative_prompt_embeds.expand(n, -1, -1).contiguous() if negative_prompt_embeds.shape[0] == 1 else negative_prompt_embeds[:n])
+        extra = dict(warp_cond=torch.cat(wc, 0).contiguous()) if wc else {}
+        res = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=torch.cat(cc, 0).contiguous(),
+                   flow_cond=torch.cat(fc, 0).contiguous(), latents=torch.cat(lt, 0).contiguous(),
+                   output_type="latent" if output == "latent" else "pt", **extra, **pipe_kwargs).images
+        outs.append(res.float())
+    return torch.cat(outs, 0).contiguous()
+
+
+def gather_units(local, my_units, num_units, dst=0):
+    """Collect per-unit tensors [n_local, ...] on `dst` in unit order (optional; see module docstring)."""
+    ids = [u.uid for u in my_units]
+    if not torch.distributed.is_available() or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+        out = torch.empty((num_units,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        out[ids] = local
+        return out
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object((ids, local.cpu()), gathered, dst=dst)          # ragged shares: object gather (decoded frames only)
+    if rank != dst:
+        return None
+    out = torch.empty((num_units,) + tuple(local.shape[1:]), dtype=local.dtype)
+    for r_ids, r_t in gathered:
+        if len(r_ids):
+            out[r_ids] = r_t
+    return out
+
+
+def blend_frames(unit_images, units, height, width, overlap=64):
+    """fp32 unit images [n,3,th,tw] in [0,1] of COMPLETE frames -> {frame: uint8 [H,W,3]} (device blend kernel when the
+    tensors live on the GPU, `tiling.merge_ramp` on the host otherwise)."""
+    import numpy as np
+
+    from . import ops, tiling
+    frames = {}
+    by_frame = {}
+    for k, u in enumerate(units):
+        by_frame.setdefault(u.frame, []).append((u.tile, k, u.window))
+    for f, lst in by_frame.items():
+        lst.sort()
+        idx = [k for _, k, _ in lst]
+        coords = [w for _, _, w in lst]
+        tiles = unit_images[idx].contiguous()
+        if len(lst) == 1 and coords[0] == (0, height, 0, width):
+            frames[f] = (tiles[0].permute(1, 2, 0) * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+        elif tiles.is_cuda:
+            frames[f] = ops.blend_tiles_ramp(tiles, coords, (height, width), overlap).cpu().numpy()
+        else:
+            host = [np.asarray(t.permute(1, 2, 0).numpy() * 255.0, np.float32) for t in tiles]
+            frames[f] = tiling.merge_ramp(host, coords, (height, width), order="hwc", feather=overlap)
+    return frames
+
+
+@torch.no_grad()
+def decode_clip(pipe, source, num_frames, gop_size, height, width, prompt_embeds, negative_prompt_embeds=None, *, tile=512,
+                overlap=64, batch=16, seed=0, rank=None, world=None, shard_mode="unit", gather=True, **pipe_kwargs):
+    """Whole pipeline for one clip on this rank.  Returns dict(units=all units, mine=this rank's, images=this rank's fp32 unit
+    images, frames={frame: uint8 HxWx3} on the gathering rank (or for locally complete frames when gather=False))."""
+    if rank is None or world is None:
+        ini = torch.distributed.is_available() and torch.distributed.is_initialized()
+        rank = torch.distributed.get_rank() if ini else 0
+        world = torch.distributed.get_world_size() if ini else 1
+    units = plan_units(num_frames, gop_size, height, width, tile, overlap)
+    mine = shard(units, rank, world, shard_mode)
+    images = decode_units(pipe, mine, source, prompt_embeds, negative_prompt_embeds, batch=batch, seed=seed,
+                          frame_size=(height, width), **pipe_kwargs)
+    frames = None
+    if gather and world > 1:
+        allimg = gather_units(images, mine, len(units), dst=0)
+        if rank == 0:
+            frames = blend_frames(allimg, units, height, width, overlap)
+    else:
+        per_frame = {}
+        for u in units:
+            per_frame[u.frame] = per_frame.get(u.frame, 0) + 1
+        have = {}
+        for u in mine:
+            have[u.frame] = have.get(u.frame, 0) + 1
+        complete = [k for k, u in enumerate(mine) if have[u.frame] == per_frame[u.frame]]
+        if complete:
+            frames = blend_frames(images[complete], [mine[k] for k in complete], height, width, overlap)
+    return dict(units=units, mine=mine, images=images, frames=frames)

@@ -69,6 +69,8 @@ class BiDirFeatureExtractor:
 
 
 class HipDualFlowControlNet:
+    needs_warp_cond = False                # ResControlNet (flow_resnet.py:58) overrides
+
     def __init__(self, state_dict, config=None, device="cuda"):
         cfg = dict(weights.SD15_UNET_CONFIG if config is None else config)
         self.cfg = cfg
@@ -112,19 +114,20 @@ class HipDualFlowControlNet:
         self._ctx_keepalive = ctx
 
     # ---- step-invariant part ------------------------------------------------------------------------------
-    def compute_pyramid(self, controlnet_cond, flow_cond):
+    def compute_pyramid(self, controlnet_cond, flow_cond, warp_cond=None):
         """flownet.py:78 -> (P64,P32,P16,P08) NCHW fp32 (exposed for parity tests)."""
         cond = controlnet_cond.to(device=self.device, dtype=torch.float32).contiguous()
         flow = flow_cond.to(device=self.device, dtype=torch.float32).contiguous()   # kept fp32: see module docstring
         return self.feature_extractor(cond, flow)
 
-    def prepare_controls(self, controlnet_cond, flow_cond):
-        """Pyramid + FDN gamma/beta (control_utils.py:31-32) at the controls' own batch size; cached by identity."""
-        key = (controlnet_cond.data_ptr(), flow_cond.data_ptr(), tuple(controlnet_cond.shape), controlnet_cond._version,
-               flow_cond._version)
+    def prepare_controls(self, controlnet_cond, flow_cond, warp_cond=None):
+        """Pyramid + FDN gamma/beta (control_utils.py:31-32) at the controls' own batch size; cached by identity
+        (pointer, shape and in-place version of EVERY control tensor, `warp_cond` of the ResControlNet included).  The
+        gamma/beta buffers keep their addresses across calls (captured hipGraphs read them)."""
+        key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (controlnet_cond, flow_cond, warp_cond) if t is not None)
         if key == self._ctrl_key:
             return self.gamma_beta
-        pyr = self.compute_pyramid(controlnet_cond, flow_cond)
+        pyr = self.compute_pyramid(controlnet_cond, flow_cond, warp_cond)
         gb = []
         for lvl, (cg, cb) in zip(pyr, self.fdn):
             p = ops.nchw_f32_to_nhwc_bf16(lvl)
@@ -137,8 +140,8 @@ class HipDualFlowControlNet:
         else:
             self.gamma_beta = gb
         self._ctrl_key = key
-        self._ctrl_keepalive = (controlnet_cond, flow_cond)
-        return gb
+        self._ctrl_keepalive = (controlnet_cond, flow_cond, warp_cond)
+        return self.gamma_beta
 
     # ---- per-step part ---------------------------------------------------------------------------------------
     def _fdn(self, sample, level):

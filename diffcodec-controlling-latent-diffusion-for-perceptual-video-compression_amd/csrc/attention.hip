@@ -41,8 +41,11 @@ struct AttnArgs {
 // SHORT (Nk <= 2 * KV_TILE, i.e. the 77-token text context of every cross-attention): both key tiles are staged once
 // and stay in the two LDS buffers while the workgroup walks over SHORT_PASSES query blocks — no barrier, no K/V traffic
 // and no staging latency per block; the long form pays all three once per 128*QB queries for two iterations of work.
+// RAGGED: Nk is not a multiple of KV_TILE — only then does the key-masking code exist at all (left in the common kernel,
+// hipcc speculates its ~90 index/compare/select VALU instructions into every tile although they matter in the last one
+// only; the d = 40 kernel is VALU-issue-bound, so that was a quarter of its time).
 constexpr int SHORT_PASSES = 4;
-template <int D, int QB, bool SHORT>
+template <int D, int QB, bool SHORT, bool RAGGED>
 __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
 {
     constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     constexpr int NLD = (KV_TILE * NV + 255) / 256;  // vectors per thread per operand per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;
     constexpr int QWG = 4 * QW * (SHORT ? SHORT_PASSES : 1);   // queries per workgroup
     const int qblocks = (a.Nq + QWG - 1) / QWG;
@@ -120,19 +123,20 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     u32x4 rk[NLD], rv[NLD];
     const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
 
+    // Staging: lane -> key (consecutive lanes, consecutive keys), wave + 4i -> 16-byte vector of the row, so "this wave has a
+    // vector to move" is a scalar (wave-uniform) test and the loads run without an exec mask; keys past Nk (ragged last tile
+    // only) re-read the last key: their scores are masked to -inf below and their probabilities are exactly 0.
     auto issue_loads = [&](int t) {
         const int kb = t * KV_TILE;
+        int key = kb + lane;
+        if (RAGGED) key = key < a.Nk ? key : a.Nk - 1;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
-            const int key = idx & 63, vec = idx >> 6;       // consecutive lanes -> consecutive keys
-            u32x4 kk = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (vec < NV && kb + key < a.Nk) {
-                kk = *(const u32x4*)(K + (long long)(kb + key) * a.ks + vec * 8);
-                vv = *(const u32x4*)(V + (long long)(kb + key) * a.vs + vec * 8);
+            const int vec = wave + 4 * i;
+            if (vec < NV) {
+                rk[i] = *(const u32x4*)(K + (long long)key * a.ks + vec * 8);
+                rv[i] = *(const u32x4*)(V + (long long)key * a.vs + vec * 8);
             }
-            rk[i] = kk;
-            rv[i] = vv;
         }
     };
     auto store_lds = [&](int buf) {
@@ -140,11 +144,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         char* sV = sK + K_BYTES;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + 256 * i;
-            const int key = idx & 63, vec = idx >> 6;
+            const int vec = wave + 4 * i;
             if (vec < NV) {
-                *(u32x4*)(sK + key * K_PITCH + vec * 16) = rk[i];
-                *(u32x4*)(sV + key * V_PITCH + vec * 16) = rv[i];
+                *(u32x4*)(sK + lane * K_PITCH + vec * 16) = rk[i];
+                *(u32x4*)(sV + lane * V_PITCH + vec * 16) = rv[i];
             }
         }
     };
@@ -152,6 +155,9 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     __syncthreads();                  // zero-fill (and the ones column) complete before the first tile lands
     issue_loads(0);
     store_lds(0);
+    // every prologue load (the Q fragments too) has landed before the loop: otherwise hipcc's wait for Q sits INSIDE the loop
+    // as vmcnt(0) in front of the first QK^T MFMA and drains the next tile's prefetch on every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0) only
     __syncthreads();
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         bf16x8 pf[QB][2][2];
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
-            if (kb + KV_TILE > a.Nk) {
+            if (RAGGED && kb + KV_TILE > a.Nk) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -197,7 +203,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[u][j][r]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            {   // exchange with lane ^ 32 on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+                mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             const float m_new = fmaxf(m_run[u], mloc);
             const float mc = m_new * a.scale_log2e;
             float lsum = 0.f;
@@ -336,20 +345,27 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
 }
 
-template <int D, int QB, bool SHORT>
-int launch_qb(const AttnArgs& a, hipStream_t st)
+template <int D, int QB, bool SHORT, bool RAGGED>
+int launch_qb_r(const AttnArgs& a, hipStream_t st)
 {
     constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
     constexpr int KP16 = (ND16 * 2) | 1;
     constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
     const size_t lds = 2 * BUF + (SHORT ? 4 * (32 * QB) * (D * 2 + 16) : 0);
-    auto kern = attn_kernel<D, QB, SHORT>;
+    auto kern = attn_kernel<D, QB, SHORT, RAGGED>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
     constexpr int QWG = 128 * QB * (SHORT ? SHORT_PASSES : 1);
     const int qblocks = (a.Nq + QWG - 1) / QWG;
     hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);
     return dc_launch_status();
+}
+
+template <int D, int QB, bool SHORT>
+int launch_qb(const AttnArgs& a, hipStream_t st)
+{
+    if (SHORT || (a.Nk % KV_TILE) != 0) return launch_qb_r<D, QB, SHORT, true>(a, st);
+    return launch_qb_r<D, QB, SHORT, false>(a, st);
 }
 
 template <int D>

@@ -20,6 +20,10 @@
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
 
+#ifndef DC_CONV_PIPE
+#define DC_CONV_PIPE 1          // developer A/B switch for the scheduled K-step (see `mfma_frags`)
+#endif
+
 namespace {
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -184,7 +188,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int tap, int buf) {
+    // One K-step (tap): all 2 x (TN + TM) fragment reads first (two register sets), then the step's LDS-DMA pieces, which
+    // the schedule spreads between the MFMAs — same reasoning as gemm_dma.hip's K-step.
+    bf16x8 wf[2][TN], xf[2][TM];
+    auto load_frags = [&](int tap, int buf) {
         const char* sB = sB0 + buf * B_BYTES;
         const int ky = tap / 3, kx = tap - 3 * ky;
         int prow[TM];                                   // halo pixel feeding this lane's output pixel, per m-tile
@@ -198,19 +205,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int qq = 4 * s + fq;
-            bf16x8 wf[TN], xf[TM];
             const int bsw = (qq ^ (fr & 7)) << 4;       // weight rows: (row & 7) == (fr & 7)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                wf[tn] = *(const bf16x8*)(sB + ((wn * TN + tn) * 16 + fr) * 128 + bsw);
-#pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-                xf[tm] = *(const bf16x8*)(sH + prow[tm] * 128 + ((qq ^ (prow[tm] & 7)) << 4));
+                xf[s][tm] = *(const bf16x8*)(sH + prow[tm] * 128 + ((qq ^ (prow[tm] & 7)) << 4));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                wf[s][tn] = *(const bf16x8*)(sB + ((wn * TN + tn) * 16 + fr) * 128 + bsw);
+        }
+    };
+    auto mfma_frags = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][tn], xf[s][tm], acc[tn][tm], 0, 0, 0);
+        if (DC_CONV_PIPE) {
+            constexpr int NMF = 2 * TN * TM;
+            constexpr int PER = NMF / (NB + 1) > 0 ? NMF / (NB + 1) : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TN + TM), 0);          // every fragment read first
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                // a few MFMAs ...
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                  // ... then one LDS-DMA piece
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NB * PER, 0);
         }
     };
 
@@ -227,9 +248,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             dc_ring_sync<NB * (NSTB - 2)>();                     // this wave's pieces of weight stage `step` have landed and its reads of
                                                                  // step-1 have returned; after the barrier everyone's have: halo image
                                                                  // visible, slot step-1 free
+            load_frags(tap, step % NSTB);
             if (tap == 0 && more_c) issue_halo(cc + 1);          // lands under the next eight K-steps
             issue_b(step + NSTB - 1, (step + NSTB - 1) % NSTB);
-            compute(tap, step % NSTB);
+            mfma_frags();
         }
         if (more_c) {
             __builtin_amdgcn_sched_barrier(0);

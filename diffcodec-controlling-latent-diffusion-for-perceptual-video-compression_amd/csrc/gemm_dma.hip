@@ -30,6 +30,10 @@
 #define DC_STAMP_AT(i)
 #endif
 
+#ifndef DC_GEMM_PIPE
+#define DC_GEMM_PIPE 1          // developer A/B switch for the scheduled K-step (see `compute`)
+#endif
+
 namespace {
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -48,6 +52,7 @@ __device__ __forceinline__ void wait_vmcnt()
 template <int TM, int TN, int NST, bool A_REG>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 {
+    constexpr bool PIPE = DC_GEMM_PIPE;
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int ROWS = BM + BN;
@@ -166,23 +171,51 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int slot) {
+    // One K-step.  All 2 x (TN + TM) fragment reads of the step are issued up front (both 32-wide k halves, two register
+    // sets), so the reads of the second half land while the MFMAs of the first run; left to itself hipcc keeps one weight
+    // fragment live at a time and waits lgkmcnt(0) in front of every group of TM MFMAs — the full LDS latency once per 4
+    // MFMAs.  The next stage's LDS-DMA pieces are issued AFTER the reads in program order (a DMA is an LDS store to the
+    // compiler: it may not sink below reads that precede it, but it may be scheduled among the MFMAs that follow it) and
+    // are spread between the MFMAs, one per few MFMAs: an LDS-DMA wave-instruction holds the wave's issue for 60-100 cycles,
+    // which a leading block of NGW of them would add to every K-step in front of the first MFMA.
+    bf16x8 wf[2][TN], xf[2][TM];
+    auto load_frags = [&](int slot) {
         const char* sA = smem + slot * STAGE;
         const char* sB = sA + BM * 128;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int swz = ((4 * s + fq) ^ (fr & 7)) << 4;
-            bf16x8 wf[TN], xf[TM];
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) wf[tn] = *(const bf16x8*)(sB + ((wn * TN + tn) * 16 + fr) * 128 + swz);
+            for (int tm = 0; tm < TM; ++tm) xf[s][tm] = *(const bf16x8*)(sA + ((wm * TM + tm) * 16 + fr) * 128 + swz);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) xf[tm] = *(const bf16x8*)(sA + ((wm * TM + tm) * 16 + fr) * 128 + swz);
+            for (int tn = 0; tn < TN; ++tn) wf[s][tn] = *(const bf16x8*)(sB + ((wn * TN + tn) * 16 + fr) * 128 + swz);
+        }
+    };
+    auto mfma_frags = [&](bool with_dma) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][tn], xf[s][tm], acc[tn][tm], 0, 0, 0);
+        if (PIPE) {
+            constexpr int NMF = 2 * TN * TM;
+            constexpr int PER = NMF / (NGW + 1) > 0 ? NMF / (NGW + 1) : 1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TN + TM), 0);          // every fragment read first
+            if (with_dma) {
+#pragma unroll
+                for (int i = 0; i < NGW; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);            // a few MFMAs ...
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);              // ... then one LDS-DMA piece
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NGW * PER, 0);
+            }
         }
+    };
+    auto compute = [&](int slot) {
+        load_frags(slot);
+        mfma_frags(false);
     };
 
     // bias for this lane's output channels: fetched now so its latency hides under the K loop
@@ -191,6 +224,26 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     for (int tn = 0; tn < TN; ++tn) {
         const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
         bv[tn] = (d.bias && nb < d.Cout) ? *(const f32x4*)(d.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // LayerNorm folded into this linear (dc_conv_desc.ln_stats): this lane's rows' (mean, rstd) and the weight column sums,
+    // fetched here next to the bias and first used in the epilogue, so the loads fly under the whole K loop (consuming them
+    // here would put a full memory round trip in front of the first DMA stage of every workgroup)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 ln_mr[TM];
+    f32x4 cs[TN];
+    if (d.ln_stats) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int m = m0 + (wm * TM + tm) * 16 + fr;
+            m = m < M ? m : M - 1;
+            ln_mr[tm] = *(const f32x2*)(d.ln_stats + (long long)m * 2);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+            cs[tn] = nb < d.Cout ? *(const f32x4*)(d.ln_colsum + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 
     // ---- pipeline
@@ -219,8 +272,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             dc_ring_sync<NGW * (NST - 2)>();              // this wave's pieces of stage k have landed and its reads of stage k-1 have
                                                           // returned; after the barrier: everyone else's too
             if (k == 0) DC_STAMP_AT(1);
+            load_frags(k % NST);
             issue_stage(kt_begin + k + NST - 1, (k + NST - 1) % NST);
-            compute(k % NST);
+            mfma_frags(true);
         }
         wait_vmcnt<0>();
     }
@@ -261,19 +315,27 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             if (d.epilogue == 1) {
 #pragma unroll
                 for (int tp = 0; tp < TN / 2; ++tp) {
-                    const f32x4 h = acc[2 * tp][tm] + bv[2 * tp];
-                    const f32x4 g = acc[2 * tp + 1][tm] + bv[2 * tp + 1];
+                    f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
+                    if (d.ln_stats) {
+                        h = (h - ln_mr[tm][0] * cs[2 * tp]) * ln_mr[tm][1];
+                        g = (g - ln_mr[tm][0] * cs[2 * tp + 1]) * ln_mr[tm][1];
+                    }
+                    h += bv[2 * tp];
+                    g += bv[2 * tp + 1];
                     bf16x4 pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
                     *(bf16x4*)(smem + row * PITCH + (((wn * TN + 2 * tp) * 16) / 2 + 4 * fq) * 2) = pk;
                 }
             } else {
+                float st1 = 0.f, st2 = 0.f;                     // partial (sum, sum of squares) of this output row: stats_out
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int nl = (wn * TN + tn) * 16 + 4 * fq;
                     const int nb = n0 + nl;
-                    f32x4 v = acc[tn][tm] + bv[tn];
+                    f32x4 v = acc[tn][tm];
+                    if (d.ln_stats) v = (v - ln_mr[tm][0] * cs[tn]) * ln_mr[tm][1];
+                    v += bv[tn];
                     if (d.row_add && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
                     if (d.act) {
 #pragma unroll
@@ -288,6 +350,19 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
                     *(bf16x4*)(smem + row * PITCH + nl * 2) = pk;
+                    if (d.stats_out && nb < d.Cout) {
+                        st1 += (v[0] + v[1]) + (v[2] + v[3]);
+                        st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+                if (d.stats_out) {                              // lanes fr, fr+16, fr+32, fr+48 hold the same row: fixed-order tree
+                    st1 += __shfl_xor(st1, 16, 64);
+                    st2 += __shfl_xor(st2, 16, 64);
+                    st1 += __shfl_xor(st1, 32, 64);
+                    st2 += __shfl_xor(st2, 32, 64);
+                    if (fq == 0 && m < M) {
+                        *(f32x2*)(d.stats_out + ((long long)m * (2 * n_tiles) + tile_n * 2 + wn) * 2) = f32x2{st1, st2};
+                    }
                 }
             }
         }
@@ -389,6 +464,13 @@ int launch_gemm(const dc_conv_desc& d, hipStream_t st)
 
 }  // namespace
 
+extern "C" int dc_gemm_row_stats_parts(int Cout)
+{
+    if (Cout <= 0) return 0;
+    const int bn = (Cout % 160 == 0) ? 160 : 128;       // the N tile dc_gemm_dma_launch picks for a plain (non-GEGLU) epilogue
+    return 2 * ((Cout + bn - 1) / bn);                  // one partial per wave column slice (two per N tile)
+}
+
 int dc_gemm_dma_supported(const dc_conv_desc& d)
 {
     return d.ksize == 1 && d.gn_ab == nullptr;
@@ -397,6 +479,10 @@ int dc_gemm_dma_supported(const dc_conv_desc& d)
 int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.Ho * d.Wo;
+    // the folded LayerNorm and the row statistics live in the staged (bf16, unsplit) epilogue only
+    if ((d.ln_stats || d.stats_out) && (d.out_f32 || d.splitk > 1)) return DC_ERR_INVALID;
+    if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;
+    if (d.stats_out && d.epilogue != 0) return DC_ERR_INVALID;
     const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
     const int bn = n160 ? 160 : 128;
     const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);

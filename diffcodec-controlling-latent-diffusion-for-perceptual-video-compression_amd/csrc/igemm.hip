@@ -412,6 +412,7 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
     const int bn = n160 ? 160 : 128;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * d.splitk;
+    if ((d.ln_stats || d.stats_out) && !dc_gemm_dma_supported(d)) return DC_ERR_INVALID;   // LDS-DMA GEMM epilogue only
     int rc;
     if (dc_gemm_dma_supported(d)) rc = dc_gemm_dma_launch(d, st);
     else if (dc_conv3x3_tile_supported(d)) rc = dc_conv3x3_tile_launch(d, st);

@@ -343,6 +343,65 @@ extern "C" int dc_fdn_modulate_nhwc_bf16(const void* x, const float* ab, const v
     return dc_launch_status();
 }
 
+// Row statistics for the LayerNorm folded into a linear (dc_conv_desc.ln_stats): (sum, sum of squares) of every row of
+// x [M][C] bf16 — used when the launch that produced x could not emit them itself.  One wave per row, 16 bytes per lane
+// and trip, fixed-order reductions.
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, long long M, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int vi = lane; vi < nv; vi += 64) {
+        const bf16x8 r = *(const bf16x8*)(x + row * C + vi * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)r[j];
+            s1 += f;
+            s2 += f * f;
+        }
+    }
+    s1 = dc_wave_sum(s1);
+    s2 = dc_wave_sum(s2);
+    if (lane == 0) {
+        stats[row * 2] = s1;
+        stats[row * 2 + 1] = s2;
+    }
+}
+
+// (sum, sum of squares) partials [M][parts][2] -> (mean, rstd) [M][2] of a LayerNorm over C channels.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partials, float* __restrict__ mr, long long M,
+                                                          int parts, float inv_c, float eps)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float* p = partials + row * parts * 2;
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < parts; ++i) {
+        a1 += p[2 * i];
+        a2 += p[2 * i + 1];
+    }
+    const float mean = a1 * inv_c;
+    mr[row * 2] = mean;
+    mr[row * 2 + 1] = rsqrtf(fmaxf(a2 * inv_c - mean * mean, 0.f) + eps);
+}
+
+extern "C" int dc_ln_finalize(const float* partials, float* mean_rstd, long long M, int parts, int C, float eps, void* stream)
+{
+    if (!partials || !mean_rstd || M <= 0 || parts <= 0 || C <= 0) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(dc_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, partials, mean_rstd, M, parts,
+                       1.0f / (float)C, eps);
+    return dc_launch_status();
+}
+
+extern "C" int dc_row_stats_bf16(const void* x, float* stats, long long M, int C, void* stream)
+{
+    if (!x || !stats || M <= 0 || C <= 0 || (C & 7)) return DC_ERR_INVALID;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(dc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, M, C);
+    return dc_launch_status();
+}
+
 extern "C" int dc_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, long long M, int C,
                                  float eps, void* stream)
 {

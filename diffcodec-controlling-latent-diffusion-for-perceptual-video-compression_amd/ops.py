@@ -43,9 +43,13 @@ class PackedConv:
     kind 'small_cin':  w bf16 [k*k][Cin][Cout]
     kind 'small_cout': w bf16 [Cout][k*k][Cin]"""
 
-    def __init__(self, weight, bias, device, geglu=False, mfma_small_cout=False):
+    def __init__(self, weight, bias, device, geglu=False, mfma_small_cout=False, ln=None):
         """mfma_small_cout: route a Cout <= 8 (multiple of 4) conv through the MFMA tile kernels anyway — one mostly
-        empty N-tile, still several times faster than the VALU direct conv when M*K is large (UNet conv_out)."""
+        empty N-tile, still several times faster than the VALU direct conv when M*K is large (UNet conv_out).
+        ln = (gamma, beta, eps) of an nn.LayerNorm that feeds this nn.Linear: folded into the weights at load time,
+        W' = W diag(gamma), b' = b + W beta (fp32, then the usual bf16 rounding of W'), plus colsum(W') of the ROUNDED
+        weights so that Linear(LN(x)) = rstd * (x W'^T - mean * colsum) + b' holds exactly for the stored operands
+        (dc_conv_desc.ln_stats / ln_colsum).  Call `conv(..., ln_stats=row statistics of x)`."""
         w = weight.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -53,6 +57,15 @@ class PackedConv:
         assert kh == kw and kh in (1, 3)
         self.cout, self.cin, self.ksize, self.geglu = cout, cin, kh, geglu
         b = None if bias is None else bias.detach().float()
+        self.ln_eps = None
+        if ln is not None:
+            assert kh == 1 and cin % 64 == 0 and cout % 16 == 0
+            gamma, beta, eps = ln
+            gamma, beta = gamma.detach().float().cpu(), beta.detach().float().cpu()
+            wb = w[:, :, 0, 0].cpu() @ beta
+            b = wb if b is None else b.cpu() + wb
+            w = w.cpu() * gamma[None, :, None, None]
+            self.ln_eps = float(eps)
         if cin <= 16:
             self.kind = "small_cin"
             wp = w.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
@@ -74,6 +87,9 @@ class PackedConv:
                     b = b[idx]
         self.w = wp.contiguous().to(device=device, dtype=BF16)
         self.bias = None if b is None else b.contiguous().to(device=device, dtype=F32)
+        self.colsum = None
+        if ln is not None:           # sums of the stored (rounded, possibly GEGLU-interleaved) rows, fp64 accumulation on the host
+            self.colsum = self.w.detach().cpu().double().sum(dim=(1, 2)).float().contiguous().to(device)
 
 
 class PackedConvF32:
@@ -105,10 +121,39 @@ def _pick_splitk(m, cout, kt, units=None):
     return divs[-1] if divs else 1
 
 
+def row_stats_parts(cout):
+    """Partials per row written by a 1x1 / linear launch with `stats_out` (dc_gemm_row_stats_parts)."""
+    return lib.load().dc_gemm_row_stats_parts(int(cout))
+
+
+def row_stats(x):
+    """(sum, sum of squares) of every row of x [..., C] bf16 -> fp32 [rows, 1, 2]: the `ln_stats` operand of a linear with a
+    folded LayerNorm when the launch that produced x could not emit the statistics itself."""
+    _chk(x, BF16, "x")
+    c = x.shape[-1]
+    m = x.numel() // c
+    st = torch.empty((m, 1, 2), device=x.device, dtype=F32)
+    lib.call("dc_row_stats_bf16", x.data_ptr(), st.data_ptr(), m, c, _stream())
+    return st
+
+
+def ln_finalize(partials, c, eps):
+    """row-statistics partials [M, parts, 2] -> (mean, rstd) [M, 2] of a LayerNorm over c channels: the `ln_stats` operand."""
+    _chk(partials, F32, "partials")
+    m, parts, two = partials.shape
+    assert two == 2
+    mr = torch.empty((m, 2), device=partials.device, dtype=F32)
+    lib.call("dc_ln_finalize", partials.data_ptr(), mr.data_ptr(), m, parts, int(c), float(eps), _stream())
+    return mr
+
+
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
-         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None):
+         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None, ln_stats=None, stats_out=None):
     """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`.  `out`: optional preallocated
-    contiguous destination (e.g. one batch half of a larger buffer) on the igemm path."""
+    contiguous destination (e.g. one batch half of a larger buffer) on the igemm path.
+    ln_stats: (mean, rstd) [M, 2] of the rows of x1 (`ln_finalize`) for a `pc` built with ln=(gamma, beta, eps): LayerNorm folded
+    into this linear.
+    stats_out: fp32 [M, row_stats_parts(cout), 2] to receive the row statistics of the OUTPUT (the next block's ln_stats)."""
     _chk(x1, BF16, "x1")
     n, h, w, c1 = x1.shape
     c2 = 0
@@ -147,6 +192,8 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         out = out.view(n, ho, wo, cout_eff)
     m = n * ho * wo
     kt = (9 if k == 3 else 1) * (pc.cin // 64)
+    if ln_stats is not None or stats_out is not None:
+        splitk = 1                          # the folded LayerNorm / row statistics live in the unsplit bf16 epilogue
     if splitk is None:
         tile3 = k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample)
         splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else kt)
@@ -157,6 +204,14 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     if residual is not None:
         _chk(residual, BF16, "residual")
         assert residual.numel() == m * pc.cout
+    if (ln_stats is None) != (pc.ln_eps is None):
+        raise ValueError("ln_stats must be given exactly when the weights carry a folded LayerNorm")
+    if ln_stats is not None:
+        _chk(ln_stats, F32, "ln_stats")
+        assert tuple(ln_stats.shape) == (m, 2) and x2 is None and gn_ab is None and k == 1
+    if stats_out is not None:
+        _chk(stats_out, F32, "stats_out")
+        assert tuple(stats_out.shape) == (m, row_stats_parts(pc.cout), 2) and k == 1 and not pc.geglu and not out_f32
     ras = 0
     if row_add is not None:
         assert row_add.dtype == F32 and row_add.is_cuda and row_add.shape == (n, pc.cout) and row_add.stride(1) == 1
@@ -166,7 +221,8 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
                  N=n, H=h, W=w, C1=c1, C2=c2, Cout=pc.cout, ksize=k, stride=stride, pad=int(pad), upsample=int(upsample),
                  Ho=ho, Wo=wo, gn_silu=int(gn_silu), epilogue=1 if pc.geglu else 0, out_f32=int(out_f32),
                  out_scale=float(out_scale), splitk=int(splitk), gn_batch=0 if gn_ab is None else gn_ab.shape[0],
-                 act=int(act), row_add_stride=int(ras))
+                 act=int(act), row_add_stride=int(ras), ln_stats=_ptr(ln_stats), ln_colsum=_ptr(pc.colsum if ln_stats is not None else None),
+                 stats_out=_ptr(stats_out))
     if PROFILE is None:
         lib.call("dc_conv_igemm_bf16", d, _stream())
     else:   # bench.py roofline leg (never active in the timed region): count launches per distinct shape and keep the

@@ -59,6 +59,10 @@ class StableDiffusionDualFlowControlNetPipeline:
     def __init__(self, vae, text_encoder, tokenizer, unet, controlnet, scheduler, safety_checker=None,
                  feature_extractor=None, image_encoder=None, requires_safety_checker: bool = True):
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        # `controlnet` is one DualFlowControlNet as in the reference (pipeline.py:110), or — BASELINE config 4, "dual ControlNet
+        # (flow + residual)" — a list/tuple [DualFlowControlNet, ResControlNet] in diffusers' MultiControlNet convention:
+        # every net sees the same sample/timestep/text and its own controls, and their residuals ADD.  The reference never
+        # combines the two nets in-repo, so this rule is this package's and is unpinned.
         self.unet, self.controlnet, self.scheduler = unet, controlnet, scheduler
         self.safety_checker, self.feature_extractor, self.image_encoder = safety_checker, feature_extractor, image_encoder
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1) if vae is not None else 8
@@ -186,6 +190,8 @@ class StableDiffusionDualFlowControlNetPipeline:
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], **kwargs):
         device = self._execution_device
         self._interrupt = False
+        nets = list(self.controlnet) if isinstance(self.controlnet, (list, tuple)) else [self.controlnet]
+        warp_cond = kwargs.pop("warp_cond", None)            # [B,3,H,W]: extra control of a ResControlNet (flow_resnet.py:58)
         # 0) checks — pipeline.py:187-192
         if controlnet_cond is None or flow_cond is None:
             raise ValueError("Provide both controlnet_cond [B,6,H,W] and flow_cond [B,4,H,W].")
@@ -226,17 +232,28 @@ class StableDiffusionDualFlowControlNetPipeline:
             raise NotImplementedError("time_cond_proj_dim is None for SD-1.5 (pipeline.py:281-286)")
         nt = len(timesteps)
         controlnet_keep = [1.0 - float(i / nt < cgs or (i + 1) / nt > cge) for i in range(nt)]    # :292-295
-        cond_base_scale = controlnet_conditioning_scale[0] if isinstance(controlnet_conditioning_scale, list) else float(controlnet_conditioning_scale)
+        if isinstance(controlnet_conditioning_scale, (list, tuple)):           # one net: first entry (:206-214); several: one per net
+            sc = [float(v) for v in controlnet_conditioning_scale]
+            base_scales = [sc[0]] if len(nets) == 1 else sc
+        else:
+            base_scales = [float(controlnet_conditioning_scale)] * len(nets)
+        if len(base_scales) != len(nets):
+            raise ValueError(f"{len(nets)} ControlNets but {len(base_scales)} conditioning scales")
+        if b_ctrl != batch_size and warp_cond is not None and warp_cond.shape[0] == 1:
+            warp_cond = warp_cond.expand(batch_size, -1, -1, -1).contiguous()
+        for net in nets:
+            if getattr(net, "needs_warp_cond", False) and warp_cond is None:
+                raise ValueError("a ResControlNet is registered: pass warp_cond [B,3,H,W] (flow_resnet.py:58).")
 
-        fused = (isinstance(self.unet, HipUNet2DConditionModel) and isinstance(self.controlnet, HipDualFlowControlNet)
+        fused = (isinstance(self.unet, HipUNet2DConditionModel) and all(isinstance(nt_, HipDualFlowControlNet) for nt_ in nets)
                  and isinstance(self.scheduler, DDIMScheduler) and callback_on_step_end is None and not guess_mode and not eta)   # eta > 0: generic loop
         if fused:
             latents = self._denoise_fused(latents, prompt_embeds, negative_prompt_embeds, controlnet_cond, flow_cond, do_cfg,
-                                          guidance_scale, cond_base_scale, controlnet_keep)
+                                          guidance_scale, base_scales, controlnet_keep, nets, warp_cond)
         else:
             latents = self._denoise_generic(latents, timesteps, prompt_embeds, negative_prompt_embeds, controlnet_cond, flow_cond,
-                                            do_cfg, guidance_scale, cond_base_scale, controlnet_keep, guess_mode, eta, generator,
-                                            callback_on_step_end, callback_on_step_end_tensor_inputs)
+                                            do_cfg, guidance_scale, base_scales, controlnet_keep, guess_mode, eta, generator,
+                                            callback_on_step_end, callback_on_step_end_tensor_inputs, nets, warp_cond)
         # 5) decode & postprocess — :390-404
         if output_type == "latent":
             image, has_nsfw = latents, None
@@ -260,9 +277,12 @@ class StableDiffusionDualFlowControlNetPipeline:
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=has_nsfw)
 
     # ---- generic loop: the reference's order of module calls (pipeline.py:308-385) -------------------------
-    def _denoise_generic(self, latents, timesteps, pe, npe, cond, flow, do_cfg, guidance, base_scale, keep, guess_mode, eta,
-                         generator, callback, cb_inputs):
+    def _denoise_generic(self, latents, timesteps, pe, npe, cond, flow, do_cfg, guidance, base_scales, keep, guess_mode, eta,
+                         generator, callback, cb_inputs, nets, warp=None):
         device = self._execution_device
+        if warp is not None:
+            warp = warp.to(device)
+        warp2 = torch.cat([warp, warp], 0) if (do_cfg and warp is not None) else warp
         text = torch.cat([npe, pe], 0).to(device) if do_cfg else pe.to(device)
         cond, flow = cond.to(device), flow.to(device)
         cond2 = torch.cat([cond, cond], 0) if do_cfg else cond
@@ -275,12 +295,19 @@ class StableDiffusionDualFlowControlNetPipeline:
             x_in = torch.cat([latents, latents], 0) if do_cfg else latents
             x_in = self.scheduler.scale_model_input(x_in, t)
             if guess_mode and do_cfg:                                                   # :323-327
-                c_in, c_text, cc, fc = self.scheduler.scale_model_input(latents, t), text_cond_only, cond, flow
+                c_in, c_text, cc, fc, wc = self.scheduler.scale_model_input(latents, t), text_cond_only, cond, flow, warp
             else:
-                c_in, c_text, cc, fc = x_in, text, cond2, flow2
-            down, mid = self.controlnet(sample=c_in, timestep=t, encoder_hidden_states=c_text, controlnet_cond=cc,
-                                        flow_cond=fc, conditioning_scale=base_scale * keep[i], guess_mode=guess_mode,
-                                        return_dict=False)
+                c_in, c_text, cc, fc, wc = x_in, text, cond2, flow2, warp2
+            down = mid = None
+            for net, base_scale in zip(nets, base_scales):
+                extra_c = dict(warp_cond=wc) if getattr(net, "needs_warp_cond", False) else {}
+                d_, m_ = net(sample=c_in, timestep=t, encoder_hidden_states=c_text, controlnet_cond=cc, flow_cond=fc,
+                             conditioning_scale=base_scale * keep[i], guess_mode=guess_mode, return_dict=False, **extra_c)
+                if down is None:
+                    down, mid = d_, m_
+                else:
+                    from .rescontrolnet import combine_residuals
+                    down, mid = combine_residuals((down, mid), (d_, m_))
             if guess_mode and do_cfg:                                                   # :353-355
                 down = [torch.cat([torch.zeros_like(d), d], 0) for d in down]
                 mid = torch.cat([torch.zeros_like(mid), mid], 0)
@@ -297,12 +324,12 @@ class StableDiffusionDualFlowControlNetPipeline:
         return latents
 
     # ---- fused loop --------------------------------------------------------------------------------------------
-    def _denoise_fused(self, latents, pe, npe, cond, flow, do_cfg, guidance, base_scale, keep):
+    def _denoise_fused(self, latents, pe, npe, cond, flow, do_cfg, guidance, base_scales, keep, nets, warp=None):
         device = self._execution_device
-        unet, cn, sched = self.unet, self.controlnet, self.scheduler
+        unet, sched = self.unet, self.scheduler
         b, c, h, w = latents.shape
         st = self._state
-        key = (b, c, h, w, do_cfg)
+        key = (b, c, h, w, do_cfg, tuple(id(n_) for n_ in nets))
         if st.get("key") != key:
             st.clear()
             st["key"] = key
@@ -318,8 +345,9 @@ class StableDiffusionDualFlowControlNetPipeline:
             st["ctx"] = ctx.to(device=device, dtype=torch.bfloat16).contiguous()
             st["ctx_src"] = (pe, npe)
         unet.set_context(st["ctx"])
-        cn.set_context(st["ctx"])
-        cn.prepare_controls(cond, flow)                       # hoisted: once per call, at batch B (shared by CFG halves)
+        for cn in nets:
+            cn.set_context(st["ctx"])
+            cn.prepare_controls(cond, flow, warp)             # hoisted: once per call, at batch B (shared by CFG halves)
         coef, ttab = sched.device_tables(device)
         if st.get("tables") != (id(sched), sched.table_version):     # new schedule: graphs captured on the old tables are stale
             self._graphs.clear()
@@ -331,15 +359,23 @@ class StableDiffusionDualFlowControlNetPipeline:
         # cross-attention, so the layers before it are computed once (same values, see TransformerBlock.__call__)
         shared = bool(do_cfg and self._cfg_shared)
 
-        def one_step(scale):
-            if scale == 0.0:
+        def run_nets(scales):
+            """every ControlNet's features for this step: [(features[12], mid feature, zero convs, zero mid, scale), ...]"""
+            out = []
+            for cn, sc_ in zip(nets, scales):
+                if sc_ == 0.0:
+                    continue
+                feats, midf = cn.forward_nhwc(st["x_in"], ttab, sc_, step_dev=st["step"], cfg_shared=shared, features_only=True)
+                out.append((feats, midf, cn.zero, cn.zero_mid, sc_))
+            return out
+
+        def one_step(scales):
+            if not any(scales):
                 # controlnet_keep = 0 outside [control_guidance_start, end] (pipeline.py:292-295,354): the reference scales
                 # every residual by 0, so adding them changes nothing — skip the ControlNet for this step
                 eps = unet.forward_nhwc(st["x_in"], ttab, None, None, step_dev=st["step"], cfg_shared=shared)
             elif not self._dual_stream:
-                feats, midf = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared, features_only=True)
-                eps = unet.forward_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared,
-                                        control=(feats, midf, cn.zero, cn.zero_mid, scale))
+                eps = unet.forward_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared, control=run_nets(scales))
             else:
                 # The ControlNet and the UNet's down path are independent until the skip additions (flownet.py:83-124 vs
                 # pipeline.py:358-367): two HIP streams, joined before the UNet mid block.  Every tensor crossing streams
@@ -348,16 +384,17 @@ class StableDiffusionDualFlowControlNetPipeline:
                 side = st.setdefault("side_stream", torch.cuda.Stream(device=device))
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    feats, midf = cn.forward_nhwc(st["x_in"], ttab, scale, step_dev=st["step"], cfg_shared=shared, features_only=True)
+                    ctl = run_nets(scales)
                 sample, res, temb = unet.encode_nhwc(st["x_in"], ttab, step_dev=st["step"], cfg_shared=shared)
                 main.wait_stream(side)
-                for t_ in feats + [midf]:
-                    t_.record_stream(main)
-                eps = unet.decode_nhwc(sample, list(res), temb, control=(feats, midf, cn.zero, cn.zero_mid, scale))
+                for feats, midf, _, _, _ in ctl:
+                    for t_ in feats + [midf]:
+                        t_.record_stream(main)
+                eps = unet.decode_nhwc(sample, list(res), temb, control=ctl)
             ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
 
         nsteps = len(sched.timesteps)
-        scales = [float(base_scale * keep[i]) for i in range(nsteps)]
+        scales = [tuple(float(bs * keep[i]) for bs in base_scales) for i in range(nsteps)]
         i = 0
         while i < nsteps:
             if self.interrupt:

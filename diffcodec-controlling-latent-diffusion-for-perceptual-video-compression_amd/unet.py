@@ -97,21 +97,24 @@ class HipUNet2DConditionModel:
         return sample, res, temb
 
     def decode_nhwc(self, sample, res, temb, down_res=None, mid_res=None, control=None):
-        """control = (features[12], mid_feature, zero_convs[12], zero_mid, scale) from
+        """control = (features[12], mid_feature, zero_convs[12], zero_mid, scale), or a list of such tuples, from
         `HipDualFlowControlNet.forward_nhwc(features_only=True)`: the ControlNet's zero-convs (flownet.py:120-128) run here
         with the skip tensor as the GEMM's residual operand — zero_conv(f) * scale + skip in one epilogue instead of a
         conv and a separate add (pipeline.py:364-365)."""
         enc = self.enc
-        if control is not None:
-            feats, mid_feat, zero, zero_mid, scale = control
-            assert down_res is None and mid_res is None and len(feats) == len(res) == len(zero)
-            res = [ops.conv(f, z, out_scale=scale, residual=r) for f, z, r in zip(feats, zero, res)]
+        controls = [] if control is None else ([control] if isinstance(control, tuple) else list(control))
+        if controls:                           # several ControlNets (config 4): their residuals add, one GEMM epilogue each
+            assert down_res is None and mid_res is None
+            for feats, _, zero, _, scale in controls:
+                assert len(feats) == len(res) == len(zero)
+                res = [ops.conv(f, z, out_scale=scale, residual=r) for f, z, r in zip(feats, zero, res)]
         elif down_res is not None:
             assert len(down_res) == len(res)
             res = [ops.add_bf16(a, b) for a, b in zip(res, down_res)]          # pipeline.py:364 residual injection
         sample = enc.run_mid(sample, temb)
-        if control is not None:
-            sample = ops.conv(mid_feat, zero_mid, out_scale=scale, residual=sample)
+        if controls:
+            for _, mid_feat, _, zero_mid, scale in controls:
+                sample = ops.conv(mid_feat, zero_mid, out_scale=scale, residual=sample)
         elif mid_res is not None:
             sample = ops.add_bf16(sample, mid_res)
         for bi, blk in enumerate(self.up):

@@ -19,6 +19,7 @@ class _RawWeight:
 
     def __init__(self, t):
         self.w, self.bias, self.cout, self.cin, self.ksize, self.geglu, self.kind = t, None, t.shape[0], t.shape[1], 1, False, "igemm"
+        self.ln_eps, self.colsum = None, None
 
 
 class VaeAttention:

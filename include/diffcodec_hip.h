@@ -96,10 +96,26 @@ typedef struct dc_conv_desc {
     int gn_batch;           /* rows of gn_ab (sample n uses row n % gn_batch) */
     int act;                /* 0 none, 1 SiLU, 2 quick-GELU x*sigmoid(1.702x) — applied after bias/row_add, before out_scale */
     long long row_add_stride; /* floats between consecutive samples of row_add (0 = Cout) */
+    /* nn.LayerNorm folded into the following nn.Linear (BasicTransformerBlock.norm1/2/3 -> attn1.to_q/k/v, attn2.to_q,
+     * ff.net.0.proj): with W' = W diag(gamma) and b' = b + W beta prepared by the caller,
+     *   Linear(LN(x)) = rstd * (x W'^T - mean * colsum(W')) + b',
+     * so the GEMM runs on the raw rows and the normalisation is two per-row scalars in the epilogue; the standalone
+     * LayerNorm pass (read + write of the whole activation) disappears.  1x1 / linear descriptors only. */
+    const float* ln_stats;  /* consumer: [M][2] fp32 (mean, rstd) of every input row (dc_ln_finalize), or NULL */
+    const float* ln_colsum; /* consumer: [Cout] fp32 sum over k of the (bf16) weight row, required with ln_stats */
+    float* stats_out;       /* producer: [M][dc_gemm_row_stats_parts(Cout)][2] partial (sum, sum sq) of every OUTPUT row, or NULL */
 } dc_conv_desc;
 int dc_conv_igemm_bf16(const dc_conv_desc* desc, void* stream);
 /* Workspace bytes needed for splitk>1 (0 otherwise). */
 long long dc_conv_igemm_ws_bytes(const dc_conv_desc* desc);
+/* Partials per output row that a 1x1 / linear launch with `stats_out` writes (one per wave column slice of the tile grid). */
+int dc_gemm_row_stats_parts(int Cout);
+/* Row statistics of a bf16 matrix x [M][C] for `ln_stats` when the producing launch cannot emit them (one partial per row):
+ * stats [M][1][2] = (sum, sum of squares). */
+int dc_row_stats_bf16(const void* x, float* stats, long long M, int C, void* stream);
+/* Partials [M][parts][2] (from `stats_out` or dc_row_stats_bf16) -> mean_rstd [M][2] = (mean, 1/sqrt(var + eps)) over C channels:
+ * the `ln_stats` operand.  One small launch per LayerNorm instead of the read + write pass over the activation. */
+int dc_ln_finalize(const float* partials, float* mean_rstd, long long M, int parts, int C, float eps, void* stream);
 
 /* Small-channel direct convs (NHWC bf16): Cin <= 8 (conv_in 4->320, VAE conv_in) and Cout <= 8
  * (conv_out 320->4, VAE conv_out 128->3 / 512->8, quant convs).  Same fusions on load as the igemm.

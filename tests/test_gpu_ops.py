@@ -280,6 +280,52 @@ def test_layer_norm(ops):
         close(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("c,mean", [(320, 0.3), (640, 2.5), (1280, -1.0)])
+def test_layer_norm_folded_into_linear(ops, c, mean):
+    """BasicTransformerBlock.norm1/2/3 -> to_q/k/v | to_q | ff.net.0.proj with the LayerNorm folded into the weights and the
+    GEMM epilogue (dc_conv_desc.ln_stats): against F.linear(F.layer_norm(x)) in fp32 on the same bf16 operands.  The row
+    statistics come (a) from dc_row_stats_bf16 and (b) from the epilogue of the producing linear (stats_out), whose partial
+    sums are also checked directly.  Row offsets well away from zero (|mean| up to 2.5 sigma) exercise the mean * colsum
+    cancellation.  Tolerance: one bf16 rounding of gamma*W instead of one of LN(x) — same order as the unfused path."""
+    g = torch.Generator().manual_seed(20)
+    m = 3 * 128 + 37                                   # ragged last M tile
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    # producer: t = a @ Wo^T + bo + res, emitting the row statistics of t
+    a_in = bf(torch.randn(1, m, c, generator=g))
+    wo = bf(torch.randn(c, c, generator=g) / math.sqrt(c))
+    bo = torch.randn(c, generator=g) * 0.1 + mean
+    res = bf(torch.randn(1, m, c, generator=g) * 1.5)
+    parts = ops.row_stats_parts(c)
+    st = torch.full((m, parts, 2), float("nan"), device=DEV)
+    t = ops.linear(a_in.to(DEV, torch.bfloat16), ops.PackedConv(wo, bo, DEV), residual=res.to(DEV, torch.bfloat16), stats_out=st)
+    tf = t.float().cpu()                                # the stored (bf16) tensor the LayerNorm sees
+    tot = st.sum(1).cpu()
+    close(tot[:, 0], tf[0].sum(-1), rtol=2e-3, atol=0.3)             # statistics of the fp32 values before the bf16 rounding
+    close(tot[:, 1], (tf[0] ** 2).sum(-1), rtol=5e-3, atol=0.5)
+    st1 = ops.row_stats(t)
+    close(st1[:, 0, 0].cpu(), tf[0].sum(-1), rtol=1e-5, atol=1e-3)
+    close(st1[:, 0, 1].cpu(), (tf[0] ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+    ln = F.layer_norm(tf, (c,), gamma, beta, 1e-5)
+    # consumer 1: plain linear without bias (to_q/k/v)
+    wq = bf(torch.randn(3 * c, c, generator=g) / math.sqrt(c))
+    ref = F.linear(ln, wq)
+    pc = ops.PackedConv(wq, None, DEV, ln=(gamma, beta, 1e-5))
+    for stats in (st, st1):
+        out = ops.linear(t, pc, ln_stats=ops.ln_finalize(stats, c, 1e-5))
+        close(out.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+    # consumer 2: GEGLU projection with bias (ff.net.0.proj)
+    w1 = bf(torch.randn(8 * c, c, generator=g) / math.sqrt(c))
+    b1 = torch.randn(8 * c, generator=g) * 0.1
+    hid, gate = F.linear(ln, w1, b1).chunk(2, -1)
+    mr = ops.ln_finalize(st1, c, 1e-5)
+    close(mr[:, 0].cpu(), tf[0].mean(-1), rtol=1e-4, atol=1e-4)
+    close(mr[:, 1].cpu(), (tf[0].var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-3, atol=1e-4)
+    out = ops.linear(t, ops.PackedConv(w1, b1, DEV, geglu=True, ln=(gamma, beta, 1e-5)), ln_stats=mr)
+    close(out.float().cpu(), hid * F.gelu(gate), rtol=3e-2, atol=3e-2)
+    with pytest.raises(ValueError):
+        ops.linear(t, pc)                               # folded weights without statistics: refused, never silently wrong
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("b,heads,nq,nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
                                              (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),
