@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — decoded frames/s of the DiffCodec decode hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--frames F] [--no-graphs]
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--config c2|c4] [--no-graphs]
 
-A "step" is one pass of the hot path over one batch of F synthetic 512x512 inter frames resident in HBM:
-control pyramid + FDN gamma/beta (once per frame), 20 DDIM steps of {DualFlowControlNet, UNet} with CFG
-(model batch 2F), CFG+DDIM update, VAE decode, postprocess.  SD-1.5 topology, random-init weights in the
-diffusers key layout (no checkpoints are reachable offline), bf16 compute with fp32 accumulation.
-N > 1: one process per GPU (torch.distributed / RCCL); frames are sharded across ranks with no data-path
-collective; rank 0 synthesises the weights and broadcasts the packed tensors once (outside the timed region).
-Prints ONE JSON line on rank 0.
+A "step" is one pass of the hot path over one batch of F synthetic inter frames resident in HBM, driven exactly as a clip is
+decoded (`clip_decode`): GOP-12 clip -> decode units -> round-robin shard over the ranks -> one batched `pipe(...)` call per
+rank: control pyramid + FDN gamma/beta (once per frame), 20 DDIM steps of {DualFlowControlNet, UNet} with CFG (model batch
+2F), CFG+DDIM update, VAE decode, postprocess.  SD-1.5 topology, random-init weights in the diffusers key layout (no
+checkpoint is reachable offline), bf16 compute with fp32 accumulation.
+  --config c2 (default)  BASELINE configs[1]: 512x512 frames, one DualFlowControlNet (the configuration `metric` is quoted on)
+  --config c4            BASELINE configs[3]: 960x512 frames = two 512x512 windows each, GOP-4, DualFlowControlNet +
+                         ResControlNet (warp_cond); frames/s counts whole 960x512 frames
+N > 1: one process per GPU (torch.distributed / RCCL); units are sharded across ranks with no data-path collective; rank 0
+synthesises the weights and broadcasts the packed tensors once (outside the timed region).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -24,24 +27,26 @@ import torch  # noqa: E402
 
 STEPS_DDIM = 20
 SIZE = 512
-# algorithmic work per decoded frame (CFG on, step-invariant parts hoisted): TFLOP
+# algorithmic work per decoded 512x512 frame (CFG on, step-invariant parts hoisted): TFLOP
 TFLOP_PER_FRAME = (20 * 2 * (803.3 + 268.6) + 30.2 + 19.9 + 2514.5) / 1000.0
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (≈6300 achievable), same guide
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_pipeline(rank, device):
+def build_pipeline(rank, device, dual=False):
     from diffcodec_amd import weights as W
     from diffcodec_amd.controlnet import HipDualFlowControlNet
     from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline
+    from diffcodec_amd.rescontrolnet import HipResControlNet
     from diffcodec_amd.scheduler import DDIMScheduler
     from diffcodec_amd.unet import HipUNet2DConditionModel
     from diffcodec_amd.vae import HipAutoencoderKL
     t0 = time.time()
-    specs = (W.unet_spec(), W.controlnet_spec(), W.vae_spec())
+    specs = [W.unet_spec(), W.controlnet_spec(), W.vae_spec()] + ([W.rescontrolnet_spec()] if dual else [])
     if rank == 0:
         sds = [W.synthesize(s, seed=i) for i, s in enumerate(specs)]
     else:   # shapes only; the packed device tensors are overwritten by the broadcast from rank 0
@@ -50,7 +55,8 @@ def build_pipeline(rank, device):
     unet = HipUNet2DConditionModel(sds[0], W.SD15_UNET_CONFIG, device)
     cn = HipDualFlowControlNet(sds[1], W.SD15_UNET_CONFIG, device)
     vae = HipAutoencoderKL(sds[2], W.SD15_VAE_CONFIG, device)
-    pipe = StableDiffusionDualFlowControlNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, controlnet=cn,
+    nets = [cn, HipResControlNet(sds[3], W.SD15_UNET_CONFIG, device)] if dual else cn
+    pipe = StableDiffusionDualFlowControlNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, controlnet=nets,
                                                      scheduler=DDIMScheduler(), safety_checker=None, feature_extractor=None)
     log(f"[rank {rank}] operators packed + uploaded in {time.time() - t0:.1f}s")
     return pipe, (sds if rank == 0 else None)
@@ -64,7 +70,7 @@ def cpu_baseline(sds, threads, device_decode=None):
     from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
     from oracle import pipeline_ref as R
     torch.set_num_threads(threads)
-    usd, csd, vsd = sds
+    usd, csd, vsd = sds[:3]
     cond, flow = synth_controls(1, SIZE)
     pe, npe = synth_text(1)
     lat = synth_latents(1, SIZE)
@@ -82,21 +88,35 @@ def cpu_baseline(sds, threads, device_decode=None):
     return out
 
 
+def latest_pmc():
+    """HBM traffic of the dominant conv shape from committed rocprofv3 --pmc passes (counters cannot be read in-process)."""
+    for name in ("r02_pmc_igemm.json", "r01_pmc_igemm.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            with open(p) as fh:
+                sh = json.load(fh)["shapes"][0]
+            return sh["hbm_bytes"], (f"HBM bytes per launch of {sh['shape']}: 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                     f"(profiles/{name}), {sh['ratio']}x its algorithmic {sh['algorithmic_bytes']} B")
+    return None, "no PMC summary committed"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=16, help="inter frames decoded per step per GPU (1 = single-frame latency config)")
+    ap.add_argument("--frames", type=int, default=None, help="decode units (512x512 windows) per step per GPU; default 16 "
+                    "(c4: 8 frames = 16 windows); 1 = single-frame latency configuration")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c2")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--steps-per-graph", type=int, default=1, help="denoising steps captured per hipGraph")
     ap.add_argument("--dual-stream", type=int, default=1, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the per-shape igemm timing leg (profiling runs)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the post-timing legs (profiling runs)")
     args = ap.parse_args()
 
-    from diffcodec_amd import ops, sharding
-    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    from diffcodec_amd import clip_decode as CD, lib, sharding
+    from diffcodec_amd.synthetic import synth_text
     rank, local, world = sharding.init_from_env()
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
@@ -105,29 +125,42 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
+    backend_world = dist.get_world_size() if dist.is_initialized() else 1
+    backend_name = dist.get_backend() if dist.is_initialized() else "none"
 
-    pipe, sds = build_pipeline(rank, device)
+    c4 = args.config == "c4"
+    pipe, sds = build_pipeline(rank, device, dual=c4)
     if world > 1:
         t0 = time.time()
-        nbytes = sharding.broadcast_params(sharding.module_param_tensors(pipe.unet, pipe.controlnet, pipe.vae))
+        mods = [pipe.unet, pipe.vae] + (list(pipe.controlnet) if c4 else [pipe.controlnet])
+        nbytes = sharding.broadcast_params(sharding.module_param_tensors(*mods))
         torch.cuda.synchronize()
-        log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s")
+        log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s over {backend_name} (world {backend_world})")
     pipe.enable_hip_graphs(not args.no_graphs, steps_per_graph=args.steps_per_graph)
     pipe.enable_dual_stream(bool(args.dual_stream))
 
-    F = args.frames
-    # two alternating input sets (distinct tensors) so that no per-call cache can carry work across steps
-    sets = []
+    # ---- the clip: units -> shard -> resident inputs.  c2: GOP-12, one 512x512 window per frame; c4: GOP-4, 960x512 = 2 windows
+    F = args.frames if args.frames is not None else 16
+    height, width, gop = (SIZE, 960, 4) if c4 else (SIZE, SIZE, 12)
+    tiles_per_frame = len(CD.plan_units(gop + 1, gop, height, width)) // (gop - 1)
+    frames_needed = -(-F * world // tiles_per_frame)
+    num_frames = 1 + -(-frames_needed // (gop - 1)) * gop
+    all_units = CD.plan_units(num_frames, gop, height, width)[:F * world]
+    mine = CD.shard(all_units, rank, world)
+    assert len(mine) == F
+    pe, npe = (t.to(device) for t in synth_text(1))
+    kw = dict(num_inference_steps=STEPS_DDIM, guidance_scale=4.5,
+              controlnet_conditioning_scale=[1.7, 1.0] if c4 else 1.7)
+    sources = []                     # two alternating input sets (distinct tensors): no per-call cache carries work across steps
     for s in range(2):
-        cond, flow = synth_controls(F, SIZE, seed=1234 + 17 * s + 1000 * rank)
-        pe, npe = synth_text(F, seed=77 + s)
-        lat = synth_latents(F, SIZE, seed=4321 + s + 1000 * rank)
-        sets.append(dict(controlnet_cond=cond.to(device), flow_cond=flow.to(device), prompt_embeds=pe.to(device),
-                         negative_prompt_embeds=npe.to(device), latents=lat.to(device)))
-    kw = dict(num_inference_steps=STEPS_DDIM, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+        src = CD.SyntheticSource(height, width, device=device, seed=1234 + 17 * s, with_warp=c4)
+        fpn = sorted({(u.frame, u.prev, u.next) for u in mine})
+        noise = {f: CD.frame_noise(f, height, width, 4321 + s).to(device) for f, _, _ in fpn}
+        sources.append(CD.ResidentSource(src, fpn, noise=noise))
 
-    def one_step(i):
-        return pipe(**sets[i % 2], **kw).images
+    def one_step(i, units=None):
+        u = mine if units is None else units
+        return CD.decode_units(pipe, u, sources[i % 2], pe, npe, batch=len(u), frame_size=(height, width), **kw)
 
     for i in range(args.warmup):
         tw = time.perf_counter()
@@ -152,26 +185,35 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
 
-    # ---- single-frame latency configuration (BASELINE configs[1] read literally: one 512x512 frame per pass), reported
-    #      beside `value`; measured after the timed region, never part of it
-    single = None
-    if rank == 0 and F != 1 and not args.no_roofline:
-        one = [{k: v[:1].contiguous() for k, v in s_.items()} for s_ in sets]
+    extras = rank == 0 and not args.no_roofline
+
+    def timed_units(units, reps=3):
         for i in range(2):
-            pipe(**one[i % 2], **kw)
+            one_step(i, units)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(3):
-            pipe(**one[i % 2], **kw)
+        for i in range(reps):
+            one_step(i, units)
         torch.cuda.synchronize()
-        single = dict(frames_per_step=1, ms_per_frame=round((time.perf_counter() - t1) / 3 * 1e3, 2))
-        single["frames_per_s"] = round(1e3 / single["ms_per_frame"], 3)
+        return (time.perf_counter() - t1) / reps * 1e3
+
+    # ---- other batch shapes of the same workload, after the timed region: one frame (BASELINE configs[1] read literally) and
+    #      one GOP-12 (its 11 inter frames) per pass
+    single = gop12 = None
+    if extras and not c4:
+        if F != 1:
+            ms = timed_units(mine[:1])
+            single = dict(frames_per_step=1, ms_per_frame=round(ms, 2), frames_per_s=round(1e3 / ms, 3))
+        if F >= 11 and F != 11:
+            ms = timed_units(mine[:11])
+            gop12 = dict(frames_per_step=11, ms_per_step=round(ms, 2), frames_per_s=round(11e3 / ms, 3),
+                         note="one GOP-12 = 11 inter frames decoded as one batch")
 
     # ---- U-Net forward alone (north_star's target is quoted on it): model batch 2F exactly as inside a denoising step
     #      (text K/V cached, CFG halves sharing their common prefix, ControlNet residuals added), graph-replayed, after the
     #      timed region.  FLOPs = the reference's algorithmic work, 803.3 GFLOP per sample-forward.
-    unet_fwd = None
-    if rank == 0 and not args.no_roofline:
+    unet_fwd = vae_enc = None
+    if extras and not c4:
         one_step(0)                                            # leaves contexts / controls / buffers of the F-frame batch in place
         st = pipe._state
         ttab = torch.full((STEPS_DDIM,), 500.0, device=device)
@@ -195,75 +237,94 @@ def main():
         unet_fwd = dict(model_batch=2 * F, ms=round(ms, 3), tflops=round(tf, 1), frac_of_bf16_peak=round(tf / PEAK_BF16_TFLOPS, 4),
                         note="U-Net forward only, 803.3 GFLOP of reference work per sample (all kernels: GEMM, attention, norms)")
         del gr, down, mid
+        # VAE encode (the latent-init decode variant, train_controlnet.py:1081 / pipeline.ipynb cell 7): 1116.7 GFLOP per frame
+        x = torch.rand((min(F, 8), SIZE, SIZE, 3), device=device).mul_(2).sub_(1).to(torch.bfloat16)
+        for _ in range(2):
+            pipe.vae.encode_moments_nhwc(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            pipe.vae.encode_moments_nhwc(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        vae_enc = dict(frames=x.shape[0], ms=round(ms, 3), frames_per_s=round(x.shape[0] * 1e3 / ms, 2),
+                       tflops=round(1.1167 * x.shape[0] / (ms * 1e-3), 1),
+                       note="AutoencoderKL.encode 512x512 -> 64x64 moments, 1116.7 GFLOP of reference work per frame")
 
-    # ---- roofline leg (after the timed region): HIP events around every MFMA implicit-GEMM launch of one eager frame
-    roof = None
-    if rank == 0 and not args.no_roofline:
-        # An eager frame is host-launch-bound (events would time the gaps), so: record every igemm launch of one eager
-        # frame, then time each DISTINCT launch shape back-to-back (10 launches between two HIP events on the launch
-        # stream) and weight by its count in the frame.
+    # ---- roofline leg (after the timed region): ONE eager step with every C-ABI launch bracketed by two HIP events on the
+    #      launch stream (lib.LaunchTimer): each kernel's own duration inside the real step — real operands, real cache
+    #      state, host launch gaps excluded.  Agrees with the rocprofv3 --kernel-trace --stats CSV under profiles/.
+    roof = families = None
+    if extras:
         pipe.enable_hip_graphs(False)
-        ops.PROFILE = {}
+        pipe.enable_dual_stream(False)                          # one stream: kernels do not overlap, durations add up
+        one_step(1)
+        torch.cuda.synchronize()
+        lib.TIMER = lib.LaunchTimer()
         one_step(0)
         torch.cuda.synchronize()
-        uniq, ops.PROFILE = ops.PROFILE, None
-        n_launches = sum(u[0] for u in uniq.values())
-        tot_ms = tot_fl = 0.0
-        rows = []
-        for label, (cnt, flops, relaunch) in uniq.items():
-            for _ in range(3):
-                relaunch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                relaunch()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
-            tot_ms += cnt * ms
-            tot_fl += cnt * flops
-            rows.append((cnt * ms, cnt, ms * 1e3, flops / (ms * 1e-3) / 1e12, label))
-        rows.sort(reverse=True)
+        timer, lib.TIMER = lib.TIMER, None
+        summ = timer.summary()
+        tot_ms = sum(f["ms"] for f in summ.values())
+        families = []
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "igemm_shapes.txt"), "w") as fh:
-            fh.write("total_ms_per_frame count us_per_launch TFLOP/s shape\n")
-            for r in rows:
-                fh.write(f"{r[0]:9.3f} {r[1]:5d} {r[2]:9.2f} {r[3]:8.1f} {r[4]}\n")
-        ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        traffic, traffic_note = None, "no PMC summary committed"
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
-        if os.path.exists(pmc):       # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
-            with open(pmc) as fh:
-                sh = json.load(fh)["shapes"][0]
-            traffic = sh["hbm_bytes"]
-            traffic_note = (f"HBM bytes per launch of {sh['shape']}: 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
-                            f"(profiles/r01_pmc_igemm.json), {sh['ratio']}x its algorithmic {sh['algorithmic_bytes']} B")
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                    traffic=traffic, traffic_note=traffic_note,
-                    kernel="dc_conv_igemm_bf16 family: conv3x3_tile_kernel / gemm_dma_kernel / igemm_kernel", launches_per_step=n_launches,
-                    avg_launch_us=round(tot_ms * 1e3 / max(1, n_launches), 2), igemm_ms_per_step=round(tot_ms, 2),
-                    note="sum of algorithmic 2*M*N*K over the igemm launches of one frame / sum of their HIP-event launch durations "
-                         "(each distinct launch shape timed back-to-back x10 on the launch stream, weighted by its count)")
+        with open(os.path.join(ROOT, "gpurun_out", "kernel_shapes.txt"), "w") as fh:
+            fh.write("# in-situ launch durations of one eager step (HIP events on the launch stream), per kernel family and shape\n")
+            for fam, f in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                tfl = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else 0.0
+                gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] else 0.0
+                families.append(dict(kernel=fam, calls=f["calls"], ms_per_step=round(f["ms"], 2), share=round(f["ms"] / tot_ms, 4),
+                                     tflops=round(tfl, 1), frac_mfma_peak=round(tfl / PEAK_BF16_TFLOPS, 4), hbm_gbs=round(gbs, 1),
+                                     frac_hbm_peak=round(gbs / PEAK_HBM_GBS, 4)))
+                fh.write(f"{f['ms']:10.3f} ms {f['calls']:6d} calls {tfl:8.1f} TFLOP/s {gbs:8.1f} GB/s  {fam}\n")
+                for shape, (cnt, ms, fl, by) in sorted(f["shapes"].items(), key=lambda kv: -kv[1][1]):
+                    if shape:
+                        fh.write(f"    {ms:9.3f} ms {cnt:5d} x {ms / cnt * 1e3:9.2f} us {fl / (ms * 1e-3) / 1e12 if ms else 0:8.1f} TFLOP/s "
+                                 f"{by / (ms * 1e-3) / 1e9 if ms else 0:8.1f} GB/s  {shape}\n")
+        dom = max((f for f in families if f["tflops"] > 50), key=lambda f: f["ms_per_step"])
+        d = summ[dom["kernel"]]
+        traffic, traffic_note = latest_pmc()
+        roof = dict(bound="mfma", achieved=dom["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=dom["frac_mfma_peak"],
+                    traffic=traffic, traffic_note=traffic_note, kernel=dom["kernel"], launches_per_step=d["calls"],
+                    avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2), kernel_ms_per_step=round(d["ms"], 2),
+                    all_kernels_ms_per_step=round(tot_ms, 2),
+                    note="dominant kernel family by time: algorithmic 2*M*N*K of its launches in one step / their summed in-situ launch "
+                         "durations (HIP events on the launch stream around every launch of one eager, single-stream step)")
+        # the HBM-bound kernels north_star asks GB/s for
+        for f in families:
+            f["bound"] = "mfma" if f["tflops"] > 50 else "hbm"
+        pipe.enable_hip_graphs(not args.no_graphs, steps_per_graph=args.steps_per_graph)
+        pipe.enable_dual_stream(bool(args.dual_stream))
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # host-core baseline: single-GPU runs only
-        dev_decode = lambda inp, kw_: pipe(**{k: v.to(device) for k, v in inp.items()}, output_type="pt", **kw_).images
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not c4:      # host-core baseline: single-GPU runs only
+        single_pipe = pipe
+        dev_decode = lambda inp, kw_: single_pipe(**{k: v.to(device) for k, v in inp.items()}, output_type="pt", **kw_).images
         cpu = cpu_baseline(sds, threads=max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("DC_CPU_THREADS", "16")))),
                            device_decode=dev_decode)
 
     if rank == 0:
-        frames = F * world * args.steps
+        units_done = F * world * args.steps
+        frames = units_done / tiles_per_frame
         fps = frames / dt
+        tflop_frame = TFLOP_PER_FRAME if not c4 else None
         line = {
-            "metric": "decoded frames/sec @ 512x512, 20-step DDIM, GOP-12",
+            "metric": "decoded frames/sec @ 512x512, 20-step DDIM, GOP-12" if not c4 else
+                      "decoded frames/sec @ 960x512 (2 x 512x512 windows), 20-step DDIM, GOP-4, dual ControlNet",
             "value": round(fps, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"512x512 inter frames, {F} per step per GPU, 20-step DDIM, CFG 4.5 (model batch {2 * F}), "
-                                   f"control scale 1.7, SD-1.5 + DualFlowControlNet + VAE decode, random-init weights",
-                       "frames_per_step_per_gpu": F, "hip_graphs": not args.no_graphs, "parallelism": f"frame-shard x{world}"},
-            "frame_tflop_algorithmic": round(TFLOP_PER_FRAME, 2),
-            "frame_mfma_frac": round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
-            "single_frame": single, "unet_forward": unet_fwd, "roofline": roof, "cpu_baseline": cpu,
+            "config": {"workload": (f"512x512 inter frames of a GOP-12 clip, {F} per step per GPU, 20-step DDIM, CFG 4.5 (model batch {2 * F}), "
+                                    f"control scale 1.7, SD-1.5 + DualFlowControlNet + VAE decode, random-init weights") if not c4 else
+                                   (f"960x512 inter frames of a GOP-4 clip as {F} 512x512 windows per step per GPU, 20-step DDIM, CFG 4.5, "
+                                    f"DualFlowControlNet (1.7) + ResControlNet (1.0, warp_cond) + VAE decode, random-init weights"),
+                       "frames_per_step_per_gpu": F / tiles_per_frame, "units_per_step_per_gpu": F, "hip_graphs": not args.no_graphs,
+                       "parallelism": f"unit-shard x{world}", "backend": backend_name, "backend_world_size": backend_world},
+            "frame_tflop_algorithmic": None if c4 else round(TFLOP_PER_FRAME, 2),
+            "frame_mfma_frac": None if c4 else round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
+            "single_frame": single, "gop12_batch": gop12, "unet_forward": unet_fwd, "vae_encode": vae_enc,
+            "roofline": roof, "kernel_families": families, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -103,6 +103,27 @@ class SyntheticSource:
         return torch.rand(1, 3, self.h, self.w, generator=g).to(self.device)
 
 
+class ResidentSource:
+    """Controls already resident in HBM (bench.py: inputs are on the device when the timed region starts): wraps another
+    source and keeps what it returned, per frame."""
+
+    def __init__(self, source, frames_prev_next, noise=None):
+        """noise: optional {frame: latents [1,4,H/8,W/8] on the device} (otherwise `frame_noise` draws per call on the host)."""
+        self.with_warp = getattr(source, "with_warp", False)
+        self._c = {f: source.controls(f, p, n) for f, p, n in frames_prev_next}
+        self._w = {f: source.warp(f) for f, _, _ in frames_prev_next} if self.with_warp else {}
+        self._n = noise
+
+    def noise(self, frame, height, width, seed):
+        return None if self._n is None else self._n[frame]
+
+    def controls(self, frame, prev, nxt):
+        return self._c[frame]
+
+    def warp(self, frame):
+        return self._w[frame]
+
+
 def frame_noise(frame, height, width, seed, channels=4):
     """Initial latents of a frame [1,4,H/8,W/8]: a CPU generator seeded per frame (pipeline.py:269-278 draws on the
     generator's device), so the result does not depend on which rank / batch decodes the frame."""
@@ -126,7 +147,8 @@ def decode_units(pipe, units, source, prompt_embeds, negative_prompt_embeds=None
             cond, flow = source.controls(u.frame, u.prev, u.next)
             h, w = (cond.shape[-2], cond.shape[-1]) if frame_size is None else frame_size
             warp = source.warp(u.frame) if getattr(source, "with_warp", False) else None
-            cache[u.frame] = (cond, flow, frame_noise(u.frame, h, w, seed), warp)
+            nz = source.noise(u.frame, h, w, seed) if hasattr(source, "noise") else None
+            cache[u.frame] = (cond, flow, frame_noise(u.frame, h, w, seed) if nz is None else nz, warp)
         return cache[u.frame]
 
     outs = []

@@ -40,7 +40,17 @@ __device__ __forceinline__ float dc_erf_fast(float x)
     const float r = 1.0f - p * t * e;
     return copysignf(r, x);
 }
-__device__ __forceinline__ float dc_gelu_erf(float x) { return 0.5f * x * (1.0f + dc_erf_fast(x * 0.70710678118654752440f)); }
+#ifndef DC_GELU_VARIANT
+#define DC_GELU_VARIANT 0       // developer experiments only (tools/bench_gemm.py A/B): 1 = identity (upper bound of what a cheaper
+#endif                          // GELU could buy), never built into the product library
+__device__ __forceinline__ float dc_gelu_erf(float x)
+{
+#if DC_GELU_VARIANT == 1
+    return x;
+#else
+    return 0.5f * x * (1.0f + dc_erf_fast(x * 0.70710678118654752440f));
+#endif
+}
 
 __device__ __forceinline__ float dc_wave_sum(float v)
 {

@@ -103,7 +103,47 @@ class HipLaunchError(RuntimeError):
     pass
 
 
-def call(name, *args):
-    rc = getattr(load(), name)(*args)
+class LaunchTimer:
+    """In-situ per-launch timing for bench.py's roofline leg (never active in a timed region): while `lib.TIMER` is set, every
+    C-ABI call is bracketed by two HIP events recorded on the launch stream (torch's current stream — the stream the launcher
+    is given), so the elapsed time is the kernel's own duration inside the real step: real operands, real cache state, host
+    launch gaps excluded.  `meta` = (family label, shape label, algorithmic FLOPs, algorithmic bytes) from the ops wrapper."""
+
+    def __init__(self):
+        self.records = []          # (name, meta, start event, end event)
+
+    def summary(self):
+        """{family: dict(calls, ms, flops, bytes, shapes={shape: [calls, ms, flops, bytes]})} — call after a device sync."""
+        out = {}
+        for name, meta, e0, e1 in self.records:
+            fam, shape, fl, by = meta if meta is not None else (name, "", 0.0, 0.0)
+            ms = e0.elapsed_time(e1)
+            f = out.setdefault(fam, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0, shapes={}))
+            f["calls"] += 1
+            f["ms"] += ms
+            f["flops"] += fl
+            f["bytes"] += by
+            sh = f["shapes"].setdefault(shape, [0, 0.0, 0.0, 0.0])
+            sh[0] += 1
+            sh[1] += ms
+            sh[2] += fl
+            sh[3] += by
+        return out
+
+
+TIMER = None
+
+
+def call(name, *args, meta=None):
+    t = TIMER
+    if t is None:
+        rc = getattr(load(), name)(*args)
+    else:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        t.records.append((name, meta, e0, e1))
     if rc != 0:
         raise HipLaunchError(f"{name} returned {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")

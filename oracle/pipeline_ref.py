@@ -136,7 +136,8 @@ class UniPCRef:
 def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flow_cond, prompt_embeds,
                  negative_prompt_embeds, latents, num_inference_steps=20, guidance_scale=7.5,
                  controlnet_conditioning_scale=1.0, output_type="pt", hoist=True, return_latents=False,
-                 control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None):
+                 control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None,
+                 res_cn_sd=None, warp_cond=None, res_conditioning_scale=None):
     """pipeline.py:144-404, `prompt_embeds=` path.  hoist=True computes the step-invariant pyramid once
     (identical values to recomputing it every step as the reference does, flownet.py:78)."""
     do_cfg = guidance_scale is not None and guidance_scale > 1.0            # pipeline.py:202
@@ -146,6 +147,16 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
     latents = latents.float() * sched.init_noise_sigma
     from . import control_ref as C
     pyr = C.bi_dir_feature_extractor(cn_sd, "feature_extractor.", controlnet_cond.float(), flow_cond.float()) if hoist else None
+    # BASELINE config 4 ("dual ControlNet (flow + residual)"): a second, ResControlNet-shaped net (flow_resnet.py:52-144) with
+    # its own controls; residuals of the two nets add (this package's rule — the reference never combines them in-repo)
+    pyr2 = None
+    if res_cn_sd is not None:
+        rp = C.bi_dir_residue_extractor(res_cn_sd, "feature_extractor.", controlnet_cond[:, :3].float(), controlnet_cond[:, 3:].float(),
+                                        flow_cond[:, :2].float(), flow_cond[:, 2:].float())
+        rw = C.warp_extractor(res_cn_sd, "warp_extractor.", warp_cond.float())
+        pyr2 = [a_ + b_ for a_, b_ in zip(rp, rw)]
+        if res_conditioning_scale is None:
+            res_conditioning_scale = controlnet_conditioning_scale
     nt = len(sched.timesteps)
     for i, t in enumerate(sched.timesteps):
         keep = 1.0 - float(i / nt < control_guidance_start or (i + 1) / nt > control_guidance_end)  # :292-295
@@ -155,6 +166,11 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
         p = [torch.cat([q, q], 0) for q in pyr] if (pyr is not None and do_cfg) else pyr
         down, mid = M.dualflow_controlnet_forward(cn_sd, unet_cfg, x_in, t, ctx, cc, fc,
                                                   controlnet_conditioning_scale * keep, pyramid=p)
+        if pyr2 is not None:
+            p2 = [torch.cat([q, q], 0) for q in pyr2] if do_cfg else pyr2
+            d2, m2 = M.dualflow_controlnet_forward(res_cn_sd, unet_cfg, x_in, t, ctx, cc, fc, res_conditioning_scale * keep,
+                                                   pyramid=p2, residual_variant=True)
+            down, mid = [a_ + b_ for a_, b_ in zip(down, d2)], mid + m2
         eps = M.unet_forward(unet_sd, unet_cfg, x_in, t, ctx, down, mid)   # :358-367
         if do_cfg:
             eu, et = eps.chunk(2)

@@ -2,6 +2,8 @@
 against the CPU oracle on identical seeded weights and inputs.  Device path is bf16 with fp32 accumulation; the
 oracle is fp32, so the bar is a relative-L2 / PSNR tolerance stated per test (north_star: "within a stated fp16
 tolerance").  Reduced-width SD-1.5 topology keeps the oracle at seconds; one test runs the true SD-1.5 widths."""
+import os
+
 import pytest
 import torch
 
@@ -478,3 +480,200 @@ def test_full_size_20_step_decode_vs_oracle():
     assert img.shape == ref_img.shape == (1, 3, 512, 512)
     assert T.rel_l2(lat_d, ref_lat) < 4e-2
     assert T.psnr(img, ref_img) > 35.0
+
+
+# ------------------------------------------------------------------------------------------- config 4 / clip driver
+def _dual_pipe(T, cfg, vcfg, usd, csd, rsd, vsd):
+    from diffcodec_amd.controlnet import HipDualFlowControlNet
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline
+    from diffcodec_amd.rescontrolnet import HipResControlNet
+    from diffcodec_amd.scheduler import DDIMScheduler
+    from diffcodec_amd.unet import HipUNet2DConditionModel
+    from diffcodec_amd.vae import HipAutoencoderKL
+    return StableDiffusionDualFlowControlNetPipeline(
+        vae=HipAutoencoderKL(vsd, vcfg, DEV), text_encoder=None, tokenizer=None, unet=HipUNet2DConditionModel(usd, cfg, DEV),
+        controlnet=[HipDualFlowControlNet(csd, cfg, DEV), HipResControlNet(rsd, cfg, DEV)], scheduler=DDIMScheduler(),
+        safety_checker=None, feature_extractor=None)
+
+
+def test_dual_controlnet_pipeline_small(small):
+    """BASELINE config 4 plumbing at reduced widths: pipe(controlnet=[DualFlowControlNet, ResControlNet], warp_cond=...) —
+    fused loop (both zero-conv sets applied in GEMM epilogues), generic loop (module calls + combine_residuals), hipGraphs
+    and two streams, per-net conditioning scales — against the oracle's loop with both nets (sum rule, unpinned)."""
+    T, _, (usd, csd, vsd) = small
+    from diffcodec_amd import weights as W
+    from oracle import pipeline_ref as R
+    rsd = W.synthesize(W.rescontrolnet_spec(T.SMALL_UNET), 5)
+    pipe = _dual_pipe(T, T.SMALL_UNET, T.SMALL_VAE, usd, csd, rsd, vsd)
+    cond, flow, pe, npe, lat = _inputs(T)
+    warp = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(9))
+    common = dict(num_inference_steps=3, guidance_scale=4.5)
+    ref = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, controlnet_conditioning_scale=1.7,
+                         res_cn_sd=rsd, warp_cond=warp, res_conditioning_scale=0.8, **common)
+    one = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, controlnet_conditioning_scale=1.7, **common)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, warp_cond=warp,
+              controlnet_conditioning_scale=[1.7, 0.8], output_type="pt", **common)
+    img = pipe(**kw).images.float().cpu()
+    assert T.psnr(img, ref) > 30.0
+    assert T.psnr(ref, one) < 40.0                              # the second net really changes the frame
+    img_g = pipe(**kw, callback_on_step_end=lambda p, i, t, d: d).images.float().cpu()      # generic loop
+    assert T.psnr(img_g, ref) > 30.0
+    pipe.enable_hip_graphs(True)
+    pipe.enable_dual_stream(True)
+    try:
+        a = pipe(**kw).images.float().cpu()
+        b = pipe(**kw).images.float().cpu()
+    finally:
+        pipe.enable_hip_graphs(False)
+        pipe.enable_dual_stream(False)
+    assert torch.equal(a, img) and torch.equal(b, img)           # same launches, same order per stream: bit-identical
+    with pytest.raises(ValueError, match="warp_cond"):
+        pipe(**{k: v for k, v in kw.items() if k != "warp_cond"})
+    with pytest.raises(ValueError, match="conditioning scales"):
+        pipe(**dict(kw, controlnet_conditioning_scale=[1.0, 1.0, 1.0]))
+
+
+def test_rescontrolnet_control_cache_tracks_warp_cond(small):
+    """the ResControlNet cache key must include warp_cond (pointer, shape, in-place version) and gamma/beta must keep
+    their addresses (captured hipGraphs read them)."""
+    T, _, _ = small
+    from diffcodec_amd import weights as W
+    from diffcodec_amd.rescontrolnet import HipResControlNet
+    net = HipResControlNet(W.synthesize(W.rescontrolnet_spec(T.SMALL_UNET), 5), T.SMALL_UNET, DEV)
+    cond, flow, *_ = _inputs(T)
+    cond, flow = cond.to(DEV), flow.to(DEV)
+    warp = torch.rand(1, 3, 256, 256, device=DEV)
+    gb = net.prepare_controls(cond, flow, warp)
+    ptrs = [(g.data_ptr(), b.data_ptr()) for g, b in gb]
+    first = [g.clone() for g, _ in gb]
+    assert net.prepare_controls(cond, flow, warp) is gb          # cache hit
+    warp.mul_(0.5)                                               # in-place update: version bump -> recompute into the SAME buffers
+    gb2 = net.prepare_controls(cond, flow, warp)
+    assert [(g.data_ptr(), b.data_ptr()) for g, b in gb2] == ptrs
+    assert any(not torch.equal(a, g) for a, (g, _) in zip(first, gb2))
+
+
+def test_clip_driver_gop12_and_tiled_frame(small):
+    """The GOP / tile driver on the device (single rank): one synthetic GOP-12 (11 inter-frame units, batched 4+4+3) equals
+    frame-by-frame pipe calls; a 2x2-tile frame at config 5's 50 DDIM steps blends to one uint8 frame."""
+    T, pipe, _ = small
+    from diffcodec_amd import clip_decode as CD
+    pe, npe = T.synth_text(1, dim=T.SMALL_UNET["cross_attention_dim"])
+    pe, npe = pe.to(DEV), npe.to(DEV)
+    src = CD.SyntheticSource(256, 256, device=DEV)
+    kw = dict(num_inference_steps=2, guidance_scale=4.5, controlnet_conditioning_scale=1.7)
+    out = CD.decode_clip(pipe, src, 13, 12, 256, 256, pe, npe, tile=256, batch=4, seed=5, rank=0, world=1, **kw)
+    assert len(out["units"]) == 11 and sorted(out["frames"]) == list(range(1, 12)) and out["frames"][3].shape == (256, 256, 3)
+    for f in (1, 7, 11):
+        cond, flow = src.controls(f, 0, 12)
+        one = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow,
+                   latents=CD.frame_noise(f, 256, 256, 5), output_type="pt", **kw).images.float().cpu()
+        got = torch.from_numpy(out["frames"][f]).permute(2, 0, 1).float() / 255.0
+        assert T.psnr(got, one[0]) > 38.0                        # batch of 4 vs batch of 1: split-K choices differ, + uint8 rounding
+    # config 5: (frame, tile) units, 50 steps, tiles blended on the device
+    src2 = CD.SyntheticSource(448, 448, device=DEV)
+    t = CD.decode_clip(pipe, src2, 3, 2, 448, 448, pe, npe, tile=256, overlap=64, batch=4, seed=5, rank=0, world=1,
+                       num_inference_steps=50, guidance_scale=4.5, controlnet_conditioning_scale=1.7)
+    assert len(t["units"]) == 4 and [u.window for u in t["units"]] == [(0, 256, 0, 256), (0, 256, 192, 448), (192, 448, 0, 256), (192, 448, 192, 448)]
+    fr = t["frames"][1]
+    assert fr.shape == (448, 448, 3) and fr.dtype.name == "uint8" and 5 < fr.mean() < 250
+    tiles = t["images"].cpu()
+    assert torch.isfinite(tiles).all()
+    corner = torch.from_numpy(fr[:128, :128]).permute(2, 0, 1).float() / 255.0      # outside every overlap: tile 0 verbatim
+    assert (corner - tiles[0, :, :128, :128]).abs().max().item() <= 0.5 / 255 + 1e-6
+
+
+def test_config4_full_size_960x512_gop4_vs_oracle():
+    """BASELINE config 4 end to end at true SD-1.5 widths: 960x512 frames as two 512x512 windows (x = 0 and 448), GOP-4 (3 inter
+    frames -> 6 units), DualFlowControlNet + ResControlNet with warp_cond, through the clip driver; every unit against the
+    oracle's fp32 loop with both nets, and the blended frames against the host blend of the oracle's tiles.  2 DDIM steps keep
+    the CPU side under a minute."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import numpy as np
+    from diffcodec_amd import clip_decode as CD, selftest as T, tiling, weights as W
+    from diffcodec_amd.synthetic import synth_text
+    from oracle import pipeline_ref as R
+    cfg, vcfg = W.SD15_UNET_CONFIG, W.SD15_VAE_CONFIG
+    usd, csd = W.synthesize(W.unet_spec(cfg), 0), W.synthesize(W.controlnet_spec(cfg), 1)
+    rsd, vsd = W.synthesize(W.rescontrolnet_spec(cfg), 3), W.synthesize(W.vae_spec(vcfg), 2)
+    pipe = _dual_pipe(T, cfg, vcfg, usd, csd, rsd, vsd)
+    pipe.enable_hip_graphs(True)
+    pipe.enable_dual_stream(True)
+    pe, npe = synth_text(1)
+    h, w = 512, 960
+    src = CD.SyntheticSource(h, w, device=DEV, with_warp=True)
+    kw = dict(num_inference_steps=2, guidance_scale=4.5)
+    out = CD.decode_clip(pipe, src, 5, 4, h, w, pe.to(DEV), npe.to(DEV), batch=6, seed=21, rank=0, world=1,
+                         controlnet_conditioning_scale=[1.7, 1.0], **kw)
+    units = out["units"]
+    assert [(u.frame, u.window) for u in units] == [(f, wd) for f in (1, 2, 3) for wd in ((0, 512, 0, 512), (0, 512, 448, 960))]
+    imgs = out["images"].cpu()
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    ref_tiles = []
+    for k, u in enumerate(units):
+        cond, flow = (t.cpu() for t in src.controls(u.frame, u.prev, u.next))
+        warp = src.warp(u.frame).cpu()
+        y1, y2, x1, x2 = u.window
+        lat = CD.frame_noise(u.frame, h, w, 21)[:, :, y1 // 8:y2 // 8, x1 // 8:x2 // 8]
+        ref = R.decode_frame(usd, csd, vsd, cfg, vcfg, cond[:, :, y1:y2, x1:x2], flow[:, :, y1:y2, x1:x2], pe, npe, lat,
+                             controlnet_conditioning_scale=1.7, res_cn_sd=rsd, warp_cond=warp[:, :, y1:y2, x1:x2],
+                             res_conditioning_scale=1.0, **kw)
+        ref_tiles.append(ref[0])
+        p = T.psnr(imgs[k:k + 1], ref)
+        assert p > 32.0, (k, p)
+    for fi, f in enumerate((1, 2, 3)):
+        host = [np.asarray(t.permute(1, 2, 0).numpy() * 255.0, np.float32) for t in ref_tiles[2 * fi:2 * fi + 2]]
+        want = tiling.merge_ramp(host, [u.window for u in units[2 * fi:2 * fi + 2]], (h, w), order="hwc", feather=64)
+        got = out["frames"][f]
+        assert got.shape == (h, w, 3)
+        assert T.psnr(torch.from_numpy(got.astype(np.float32)), torch.from_numpy(want.astype(np.float32)), peak=255.0) > 32.0
+
+
+# ------------------------------------------------------------------------------------------- VAE encode (a15)
+def test_full_size_vae_encode_sample_and_latent_init_decode():
+    """AutoencoderKL.encode at true SD-1.5 widths, 512x512 -> 64x64 (train_controlnet.py:1081; pipeline.ipynb cell 7): the
+    asymmetric-pad stride-2 downsamples at 128 / 256 / 512 channels, `.latent_dist.sample()` with a seeded CPU generator against
+    the oracle's mean + exp(0.5 logvar) * noise on the same draw, `.mode()`, and the notebook's cells 7-8 flow:
+    latents = sample * scaling_factor * init_noise_sigma -> pipe(latents=...) (reduced-width UNet/ControlNet, full VAE)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import selftest as T, weights as W
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline
+    from diffcodec_amd.controlnet import HipDualFlowControlNet
+    from diffcodec_amd.scheduler import DDIMScheduler
+    from diffcodec_amd.unet import HipUNet2DConditionModel
+    from diffcodec_amd.vae import HipAutoencoderKL
+    from diffcodec_amd.synthetic import synth_controls, synth_text
+    from oracle import pipeline_ref as R, sd15_ref as M
+    vcfg = W.SD15_VAE_CONFIG
+    vsd = W.synthesize(W.vae_spec(vcfg), 2)
+    vae = HipAutoencoderKL(vsd, vcfg, DEV)
+    g = torch.Generator().manual_seed(17)
+    x = torch.nn.functional.avg_pool2d(torch.rand(1, 3, 512, 512, generator=g), 5, 1, 2) * 2 - 1
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    mean, logvar = M.vae_encode_moments(vsd, vcfg, x)
+    dist = vae.encode(x.to(DEV)).latent_dist
+    mom = dist.moments_nhwc.float().cpu().permute(0, 3, 1, 2)
+    assert tuple(mom.shape) == (1, 8, 64, 64)
+    assert T.rel_l2(mom[:, :4], mean) < 4e-2 and T.rel_l2(mom[:, 4:], logvar) < 4e-2
+    assert T.rel_l2(dist.mode().cpu(), mean) < 4e-2
+    noise = torch.randn((1, 4, 64, 64), generator=torch.Generator().manual_seed(123))
+    ref_s = M.vae_encode_sample(vsd, vcfg, x, noise)
+    got_s = dist.sample(generator=torch.Generator().manual_seed(123)).cpu()
+    assert (ref_s - mean).abs().mean() > 1e-3                                  # the noise term is really there
+    assert T.rel_l2(got_s, ref_s) < 4e-2
+    # cells 7-8: the encoded frame as initial latents of a decode
+    usd, csd, _ = T.small_state_dicts()
+    pipe = StableDiffusionDualFlowControlNetPipeline(vae=vae, text_encoder=None, tokenizer=None,
+                                                     unet=HipUNet2DConditionModel(usd, T.SMALL_UNET, DEV),
+                                                     controlnet=HipDualFlowControlNet(csd, T.SMALL_UNET, DEV), scheduler=DDIMScheduler(),
+                                                     safety_checker=None, feature_extractor=None)
+    cond, flow = synth_controls(1, 512)
+    pe, npe = synth_text(1, dim=T.SMALL_UNET["cross_attention_dim"])
+    kw = dict(num_inference_steps=2, guidance_scale=4.0, controlnet_conditioning_scale=1.85)
+    lat_dev = got_s * vae.config.scaling_factor * pipe.scheduler.init_noise_sigma
+    img = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat_dev, output_type="pt",
+               **kw).images.float().cpu()
+    ref = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, vcfg, cond, flow, pe, npe, ref_s * vcfg["scaling_factor"], **kw)
+    assert T.psnr(img, ref) > 30.0

@@ -70,3 +70,41 @@ def test_bi_dir_residue_extractor_512(golden_dir):
         outs = C.bi_dir_residue_extractor(sd, "", cond[:, :3], cond[:, 3:], flow[:, :2], flow[:, 2:])
     for i, o in enumerate(outs):
         torch.testing.assert_close(o, torch.from_numpy(z[f"p{i}"]), rtol=2e-4, atol=2e-5)
+
+
+def test_warp_extractor_512(golden_dir):
+    """oracle.control_ref.warp_extractor vs the reference module's outputs (extractors.py:26-65); weights regenerate from the
+    package's seeded synthesis, pinned by a checksum in the fixture."""
+    from diffcodec_amd import weights as W
+    from oracle.make_goldens import synth_warp_image
+    z = np.load(os.path.join(golden_dir, "control_warp512.npz"))
+    spec = {k[len("warp_extractor."):]: v for k, v in W.rescontrolnet_spec().items() if k.startswith("warp_extractor.")}
+    sd = W.synthesize(spec, seed=31, bf16_round=False)
+    assert abs(sum(v.double().abs().sum().item() for v in sd.values()) - float(z["w_sum"])) < 1e-9 * float(z["w_sum"])
+    x = synth_warp_image()
+    assert abs(x.double().sum().item() - float(z["x_sum"])) < 1e-9 * float(z["x_sum"])
+    with torch.no_grad():
+        outs = C.warp_extractor(sd, "", x)
+    for i, o in enumerate(outs):
+        assert tuple(o.shape) == tuple(z[f"p{i}_shape"])
+        torch.testing.assert_close(o[:, :32], torch.from_numpy(z[f"p{i}"]), rtol=2e-4, atol=2e-5)
+        assert abs(o.double().sum().item() - float(z[f"p{i}_sum"])) < 1e-5 * float(z[f"p{i}_abs"])
+
+
+def test_pyramid_hoist_equals_per_step_recompute():
+    """flownet.py:78 recomputes the pyramid in every forward; the oracle's default (and the product) computes it once per
+    frame.  Same latents either way — the pyramid takes neither the sample nor the timestep.  Reduced widths, 2 steps."""
+    from diffcodec_amd import selftest as T
+    from diffcodec_amd.synthetic import synth_latents, synth_text
+    from oracle import pipeline_ref as R
+    usd, csd, _ = T.small_state_dicts()
+    cond, flow = synth_controls(1, 512, seed=99)                    # the reference asserts the 64/32/16/8 pyramid: 512 px
+    cond, flow = cond[:, :, :128, :128].contiguous(), flow[:, :, :128, :128].contiguous()
+    pe, npe = synth_text(1, dim=T.SMALL_UNET["cross_attention_dim"])
+    lat = synth_latents(1, 128)
+    kw = dict(num_inference_steps=2, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="latent")
+    a = R.decode_frame(usd, csd, None, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, hoist=True, **kw)
+    b = R.decode_frame(usd, csd, None, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, hoist=False, **kw)
+    # equal up to fp32 summation order: the hoisted pyramid is computed at batch 1, the per-step one at the CFG batch 2, and
+    # the host conv picks a different blocking per batch size (measured 2e-5 max abs on latents of O(1))
+    torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-4)
