@@ -72,14 +72,15 @@ class ResnetBlock:
 
     def __call__(self, x, temb=None, x2=None):
         ab1 = ops.group_norm_ab(x, self.n1[0], self.n1[1], self.groups, self.eps, x2=x2)
-        h = ops.conv_gn_silu(x, self.conv1, ab1, x2=x2, row_add=None if temb is None else temb.slice(self.p, x.shape[0]))
+        h = ops.conv_gn_silu(x, self.conv1, ab1, x2=x2, row_add=None if temb is None else temb.slice(self.p, x.shape[0]),
+                             gn_part=True)                                  # norm2 reads the statistics from conv1's epilogue
         ab2 = ops.group_norm_ab(h, self.n2[0], self.n2[1], self.groups, self.eps)
         if self.shortcut is not None:
             sc = ops.conv(x, self.shortcut, x2=x2)
         else:
             assert x2 is None
             sc = x
-        return ops.conv_gn_silu(h, self.conv2, ab2, residual=sc)
+        return ops.conv_gn_silu(h, self.conv2, ab2, residual=sc, gn_part=True)   # the next block's GroupNorm input
 
 
 class TransformerBlock:
@@ -163,7 +164,7 @@ class TransformerBlock:
         f = ops.linear(t, self.ff1, ln_stats=ops.ln_finalize(st, c, 1e-5)) if fold else ops.linear(ops.layer_norm(t, *self.ln[2]), self.ff1)
         t = ops.linear(f, self.ff2, residual=t)
         if not cfg_shared:
-            return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x)
+            return ops.conv(t.reshape(n, h, w, c), self.proj_out, residual=x, gn_part=True)
         out = torch.empty((2 * n, h, w, c), device=x.device, dtype=x.dtype)
         for half in (0, 1):
             sl = slice(half * n, (half + 1) * n)
@@ -221,7 +222,7 @@ class EncoderHalf:
                     sample = a(sample)
                 res.append(sample)
             if blk["down"] is not None:
-                sample = ops.conv(sample, blk["down"], stride=2)
+                sample = ops.conv(sample, blk["down"], stride=2, gn_part=True)
                 res.append(sample)
             if after_block is not None:
                 sample = after_block(i, sample)

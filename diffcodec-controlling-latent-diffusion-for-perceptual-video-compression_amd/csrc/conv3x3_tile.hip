@@ -19,7 +19,11 @@
 // the v_mfma_f32_16x16x32_bf16 fragment ds_read_b128 are both bank-conflict-free, and rows stay whole 128-B lines.
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
+#include <cstdlib>
 
+#ifndef DC_EPI_SPECIALIZE
+#define DC_EPI_SPECIALIZE 1     // developer A/B switch: 0 = every launch takes the generic run-time-flag epilogue
+#endif
 #ifndef DC_CONV_PIPE
 #define DC_CONV_PIPE 1          // developer A/B switch for the scheduled K-step (see `mfma_frags`)
 #endif
@@ -35,9 +39,17 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TM, int TN, bool GN, int NSTB>
+// EPI: epilogue specialisation (same reasoning as gemm_dma.hip): 0 = generic run-time flags (split-K slabs, fp32 output,
+// activation), 1 = bias (+ time-embedding row) -> bf16, 2 = the same + scaled residual add.  gn_part_out stays a run-time,
+// workgroup-uniform test outside the loops.
+template <int TM, int TN, bool GN, int NSTB, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
+    constexpr bool GENERIC = EPI == 0;
+    const bool e_split = GENERIC && d.splitk > 1;
+    const bool e_res = GENERIC ? (d.residual != nullptr && d.splitk <= 1) : EPI == 2;
+    const int e_act = GENERIC ? d.act : 0;
+    const bool e_f32 = GENERIC && d.out_f32;
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * TM;                       // output rows per tile (tile is TH x 16 pixels)
     constexpr int BN = WN * TN * 16;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     for (int tn = 0; tn < TN; ++tn) {
         const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (d.splitk <= 1 && nb < d.Cout) {
+        if (!e_split && nb < d.Cout) {
             if (d.bias) v = *(const f32x4*)(d.bias + nb);
             if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)n_img * d.row_add_stride + nb);
         }
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         mrow[tm] = ((long long)n_img * d.Ho + oy) * d.Wo + ox;
     }
     bf16x4 rr[TM][TN];
-    if (d.residual && d.splitk <= 1) {
+    if (e_res) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -295,6 +307,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                                          : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
             }
     }
+    const bool want_gn = d.gn_part_out != nullptr && !e_split;
+    f32x4 gs[TN], gq[TN];                                       // GroupNorm partials of this wave's output (gn_part_out)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) gs[tn] = gq[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
@@ -303,21 +319,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             if (nb >= d.Cout) continue;
             f32x4 v = acc[tn][tm];
             const long long off = mrow[tm] * d.Cout + nb;
-            if (d.splitk > 1) {                                   // this split's own fp32 slab: plain stores, no atomics
+            if (e_split) {                                        // this split's own fp32 slab: plain stores, no atomics
                 *(f32x4*)(d.splitk_ws + (long long)blockIdx.y * slab + off) = v;
                 continue;
             }
             v += bv[tn];
-            if (d.act) {
+            if (e_act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
+                for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], e_act);
             }
             v *= d.out_scale;
-            if (d.residual) {
+            if (e_res) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
             }
-            if (d.out_f32) {
+            if (want_gn) {
+                gs[tn] += v;
+                gq[tn] += v * v;
+            }
+            if (e_f32) {
                 *(f32x4*)((float*)d.out + off) = v;
             } else {
                 bf16x4 pk;
@@ -325,6 +345,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
                 *(bf16x4*)((bf16_t*)d.out + off) = pk;
             }
+        }
+        // one pixel row group at a time: without the fence the straight-line epilogue is scheduled as one block and every
+        // tile's operands are live at once (1,700 spilled registers in the specialised kernels)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_gn) {
+        // chunk = (pixel tile within the sample, wave row); dual tiles: one wave row = one whole 8x8 image
+        const int chunk = dual ? 0 : tile_m * 2 + wm;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+            dc_gn_partial_store(gs[tn], gq[tn], d.gn_part_out + (((long long)chunk * d.N + n_img) * d.Cout + nb) * 2,
+                                fr == 0 && nb < d.Cout);
         }
     }
 }
@@ -339,16 +372,24 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
     constexpr int HALO_ROWS = TM == 4 ? 200 : (TH + 2) * 18;
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
     const size_t lds = HALO_ROWS * 128 + NSTB * BN * 128;
-#define DC_TILE_LAUNCH(GN)                                                                                      \
+    const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
+#define DC_TILE_LAUNCH1(GN, EPI)                                                                                \
     do {                                                                                                        \
-        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB>;                                                          \
+        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI>;                                                     \
         static std::atomic<unsigned long long> attr_done{0};                                                    \
         dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
     } while (0)
+#define DC_TILE_LAUNCH(GN)                          \
+    do {                                            \
+        if (epi == 1) DC_TILE_LAUNCH1(GN, 1);       \
+        else if (epi == 2) DC_TILE_LAUNCH1(GN, 2);  \
+        else DC_TILE_LAUNCH1(GN, 0);                \
+    } while (0)
     if (d.gn_ab) DC_TILE_LAUNCH(true);
     else DC_TILE_LAUNCH(false);
 #undef DC_TILE_LAUNCH
+#undef DC_TILE_LAUNCH1
     return dc_launch_status();
 }
 
@@ -362,17 +403,47 @@ int dc_conv3x3_tile_supported(const dc_conv_desc& d)
     return (d.Wo % 16) == 0 && (d.Ho % 4) == 0;
 }
 
-// Called by dc_conv_igemm_bf16 after validation (workspace already zeroed for splitk > 1).
-int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
+// Tile-shape decision shared by the launcher and the statistics-chunk query: 4 = 8-row tiles (TM = 4), 2 = 4-row tiles,
+// 8 = two whole 8x8 images per tile (TM = 4, dual).
+// N tile: 160 columns when Cout is a multiple of 160 (all SD-1.5 UNet widths).  DC_CONV_BN128=1 (developer A/B knob) takes the
+// 128-column tile instead wherever Cout is also a multiple of 128 (640, 1280): it affords a 3-stage weight ring at two
+// workgroups per CU where the 160-column tile has room for two stages only.
+static bool use_n160(const dc_conv_desc& d)
 {
-    const bool n160 = d.Cout % 160 == 0;
+    static const int force128 = getenv("DC_CONV_BN128") ? atoi(getenv("DC_CONV_BN128")) : 0;
+    return d.Cout % 160 == 0 && !(force128 && d.Cout % 128 == 0);
+}
+
+static int tile_variant(const dc_conv_desc& d)
+{
+    const bool n160 = use_n160(d);
     const int bn = n160 ? 160 : 128;
     const long long big = (long long)d.N * (d.Ho / 8) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
     // LDS budget keeps two workgroups per CU: 8-row tile with BN=160 affords a 2-stage weight ring, the others 3 stages
-    if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
+    if (d.Wo >= 16 && (d.Ho % 8) == 0 && big >= 512) return 4;
     // 8x8 maps: two images per tile when the batch is even, nothing is fused on load and enough tiles remain
     if (d.Wo == 8 && d.Ho == 8 && (d.N & 1) == 0 && !d.gn_ab &&
         (long long)(d.N / 2) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1) >= 512)   // measured: below 2 workgroups/CU the 4-row tiles win
-        return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
+        return 8;
+    return 2;
+}
+
+// gn_part_out chunks per sample of this launch (0: not available — split-K partial tiles are finished elsewhere).
+int dc_conv3x3_tile_gn_chunks(const dc_conv_desc& d)
+{
+    if (d.splitk > 1) return 0;
+    const int v = tile_variant(d);
+    if (v == 8) return 1;
+    const int sh = d.Wo < 16 ? 1 : 0;
+    const int th = (v == 4 ? 8 : 4) << sh, tw = 16 >> sh;
+    return (d.Ho / th) * (d.Wo / tw) * 2;
+}
+
+// Called by dc_conv_igemm_bf16 after validation (workspace already zeroed for splitk > 1).
+int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
+{
+    const bool n160 = use_n160(d);
+    const int v = tile_variant(d);
+    if (v == 4 || v == 8) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }

@@ -22,9 +22,12 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 __device__ __forceinline__ float dc_bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t dc_f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 
-__device__ __forceinline__ float dc_silu(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU / sigmoid forms use v_rcp_f32 (1 ulp) instead of an IEEE division: `x / (1 + e)` compiles to the ~10-instruction
+// v_div_scale / v_div_fmas / v_div_fixup sequence per element, which made the GroupNorm-apply pass and every GN-on-load halo
+// VALU-bound (gn_apply ran at 3.1 TB/s); the result is rounded to bf16 right after, 2^-16 below its last bit.
+__device__ __forceinline__ float dc_silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // dc_conv_desc.act: 1 = SiLU, 2 = quick-GELU x * sigmoid(1.702 x) (CLIP text MLP)
-__device__ __forceinline__ float dc_act(float x, int act) { return x / (1.0f + __expf(act == 2 ? -1.702f * x : -x)); }
+__device__ __forceinline__ float dc_act(float x, int act) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(act == 2 ? -1.702f * x : -x)); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the bf16 output rounding): 1 rcp + 1 exp + 7 fma
 // instead of libm erff's branchy polynomial (~3x the VALU work in the GEGLU epilogue).
 __device__ __forceinline__ float dc_erf_fast(float x)
@@ -80,6 +83,34 @@ __device__ __forceinline__ void dc_ring_sync()
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+
+// GroupNorm statistics from a conv / GEMM epilogue: `s` / `q` = this lane's (sum, sum of squares) over its pixel rows for the 4
+// channels nb..nb+3 of one 16-channel n-tile.  The 16 lanes that differ in lane bits 0-3 hold other pixels of the same
+// channels: fixed-order DPP row reduction, then the lane with bits 0-3 clear stores [4 channels][2] floats.
+// Sum over the 16 lanes of a DPP row (lanes that differ in lane bits 0-3) on the VALU: quad swaps, half-row mirror, row
+// mirror — every lane ends with the row total (each in its own, fixed association order), no LDS traffic (a `__shfl_xor`
+// compiles to ds_bpermute_b32).
+__device__ __forceinline__ float dc_row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ void dc_gn_partial_store(f32x4 s, f32x4 q, float* __restrict__ dst, bool writer)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        s[r] = dc_row16_sum(s[r]);
+        q[r] = dc_row16_sum(q[r]);
+    }
+    if (writer) {
+        *(f32x4*)dst = f32x4{s[0], q[0], s[1], q[1]};
+        *(f32x4*)(dst + 4) = f32x4{s[2], q[2], s[3], q[3]};
+    }
 }
 
 static inline int dc_launch_status()

@@ -30,6 +30,9 @@
 #define DC_STAMP_AT(i)
 #endif
 
+#ifndef DC_EPI_SPECIALIZE
+#define DC_EPI_SPECIALIZE 1     // developer A/B switch: 0 = every launch takes the generic run-time-flag epilogue
+#endif
 #ifndef DC_GEMM_PIPE
 #define DC_GEMM_PIPE 1          // developer A/B switch for the scheduled K-step (see `compute`)
 #endif
@@ -49,10 +52,25 @@ __device__ __forceinline__ void wait_vmcnt()
 // LDS-DMA.  An LDS-DMA wave-instruction costs ~100 issue cycles against ~10 for a register load + 13 for its ds_write,
 // and with both operands on DMA (9 pieces per wave per K-step) the K-loop is DMA-issue-bound (900 vs 640 MFMA cycles);
 // the hybrid issues 5.  Requires NST == 2.
-template <int TM, int TN, int NST, bool A_REG>
+// EPI: epilogue specialisation chosen by the launcher from the descriptor.  With every fusion a run-time flag, the unrolled
+// (tm, tn) epilogue was 6,300 instructions in 336 basic blocks — a branch (and often a wait) per flag per 4 outputs — and took
+// 10.7k cycles per workgroup against 9k for the whole K loop at K = 320 (phase stamps, tools/gemm_stamp.py).  The common
+// fusions are compile-time here, so their epilogues are straight-line code:
+//   0 generic (run-time flags: row_add, act, fp32 out, split-K, any mix)      1 bias        2 bias + scale + residual
+//   3 folded LayerNorm + bias                                               4 GEGLU       5 folded LayerNorm + GEGLU
+// stats_out / gn_part_out stay run-time in modes 1-2: one workgroup-uniform test outside the loops.
+template <int TM, int TN, int NST, bool A_REG, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 {
     constexpr bool PIPE = DC_GEMM_PIPE;
+    constexpr bool GENERIC = EPI == 0;
+    const bool e_geglu = GENERIC ? d.epilogue == 1 : EPI >= 4;
+    const bool e_ln = GENERIC ? d.ln_stats != nullptr : (EPI == 3 || EPI == 5);
+    const bool e_res = GENERIC ? d.residual != nullptr : EPI == 2;
+    const bool e_rowadd = GENERIC && d.row_add != nullptr;
+    const int e_act = GENERIC ? d.act : 0;
+    const bool e_stats = (GENERIC || EPI == 1 || EPI == 2) && d.stats_out != nullptr;
+    const bool e_gnpart = (GENERIC || EPI == 1 || EPI == 2) && d.gn_part_out != nullptr;
     constexpr int WM = 2, WN = 2;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int ROWS = BM + BN;
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     f32x2 ln_mr[TM];
     f32x4 cs[TN];
-    if (d.ln_stats) {
+    if (e_ln) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             int m = m0 + (wm * TM + tm) * 16 + fr;
@@ -284,18 +302,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     // ---- epilogue.  bf16 outputs go through LDS so that global stores (and residual loads) are whole 16-byte pieces of
     //      contiguous output rows: the MFMA layout gives each lane 4 channels of one pixel, i.e. 32-byte row fragments
     //      per store instruction; staged, every row leaves as BN*2 contiguous bytes.
-    const bool staged = !d.out_f32 && d.splitk <= 1;
+    const bool staged = !GENERIC || (!d.out_f32 && d.splitk <= 1);   // specialised modes are staged by construction
     if (staged) {
         constexpr int OC = BN;                                  // staged columns (GEGLU halves it below)
         constexpr int PITCH = OC * 2 + 16;                      // bytes per staged row (+16: spread rows over banks)
         static_assert(BM * PITCH <= NST * STAGE, "output tile must fit in the stage buffers");
         __syncthreads();                                        // all waves are done reading the last stage
         DC_STAMP_AT(4);
-        const int ocols = d.epilogue == 1 ? OC / 2 : OC;
         // all epilogue operands are fetched up front (independent loads in flight together): issued one (tm, tn) tile at
         // a time behind `if (bias)` / `if (residual)` they serialise into ~20 dependent L2 round trips per workgroup
         bf16x4 rr[TM][TN];
-        if (d.residual && d.epilogue == 0) {
+        if (e_res && !e_geglu) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 const int m = m0 + (wm * TM + tm) * 16 + fr;
@@ -307,16 +324,19 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 }
             }
         }
+        f32x4 gs[TN], gq[TN];                                   // GroupNorm partials over this wave's rows (gn_part_out)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) gs[tn] = gq[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int row = (wm * TM + tm) * 16 + fr;
             const int m = m0 + row;
-            const int nimg = d.row_add ? (m < M ? m : M - 1) / HoWo : 0;
-            if (d.epilogue == 1) {
+            const int nimg = e_rowadd ? (m < M ? m : M - 1) / HoWo : 0;
+            if (e_geglu) {
 #pragma unroll
                 for (int tp = 0; tp < TN / 2; ++tp) {
                     f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
-                    if (d.ln_stats) {
+                    if (e_ln) {
                         h = (h - ln_mr[tm][0] * cs[2 * tp]) * ln_mr[tm][1];
                         g = (g - ln_mr[tm][0] * cs[2 * tp + 1]) * ln_mr[tm][1];
                     }
@@ -329,20 +349,21 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 }
             } else {
                 float st1 = 0.f, st2 = 0.f;                     // partial (sum, sum of squares) of this output row: stats_out
+                const float rowmask = m < M ? 1.f : 0.f;        // rows past M are clamped duplicates: keep them out of the sums
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     const int nl = (wn * TN + tn) * 16 + 4 * fq;
                     const int nb = n0 + nl;
                     f32x4 v = acc[tn][tm];
-                    if (d.ln_stats) v = (v - ln_mr[tm][0] * cs[tn]) * ln_mr[tm][1];
+                    if (e_ln) v = (v - ln_mr[tm][0] * cs[tn]) * ln_mr[tm][1];
                     v += bv[tn];
-                    if (d.row_add && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
-                    if (d.act) {
+                    if (e_rowadd && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
+                    if (e_act) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
+                        for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], e_act);
                     }
-                    if (d.out_scale != 1.0f) v *= d.out_scale;
-                    if (d.residual) {
+                    v *= d.out_scale;
+                    if (e_res) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
                     }
@@ -350,12 +371,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
                     *(bf16x4*)(smem + row * PITCH + nl * 2) = pk;
-                    if (d.stats_out && nb < d.Cout) {
-                        st1 += (v[0] + v[1]) + (v[2] + v[3]);
-                        st2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    if (GENERIC || EPI == 1 || EPI == 2) {      // the sums are a handful of FMAs: always formed, stored on request
+                        const float cm = nb < d.Cout ? 1.f : 0.f;
+                        st1 += cm * ((v[0] + v[1]) + (v[2] + v[3]));
+                        st2 += cm * ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                        gs[tn] += rowmask * v;
+                        gq[tn] += rowmask * (v * v);
                     }
                 }
-                if (d.stats_out) {                              // lanes fr, fr+16, fr+32, fr+48 hold the same row: fixed-order tree
+                if (e_stats) {                                  // lanes fr, fr+16, fr+32, fr+48 hold the same row: fixed-order tree
                     st1 += __shfl_xor(st1, 16, 64);
                     st2 += __shfl_xor(st2, 16, 64);
                     st1 += __shfl_xor(st1, 32, 64);
@@ -366,12 +390,23 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 }
             }
         }
+        if (e_gnpart) {
+            // chunk = (row tile within the sample, wave row); the launcher guarantees HoWo % BM == 0, so a tile has one sample
+            const int n_img = m0 / HoWo;
+            const int chunk = ((m0 - n_img * HoWo) / BM) * 2 + wm;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
+                dc_gn_partial_store(gs[tn], gq[tn], d.gn_part_out + (((long long)chunk * d.N + n_img) * d.Cout + nb) * 2,
+                                    fr == 0 && nb < d.Cout);
+            }
+        }
         DC_STAMP_AT(5);
         __syncthreads();
         DC_STAMP_AT(6);
         // cooperative store: consecutive lanes -> consecutive 16-byte pieces of one output row
-        const int out_cols = d.epilogue == 1 ? d.Cout >> 1 : d.Cout;
-        const int col0 = d.epilogue == 1 ? n0 >> 1 : n0;
+        const int out_cols = e_geglu ? d.Cout >> 1 : d.Cout;
+        const int col0 = e_geglu ? n0 >> 1 : n0;
         bf16_t* __restrict__ o = (bf16_t*)d.out;
         auto store_rows = [&](auto pieces_c) {                  // 16-byte pieces per staged row: a compile-time divisor
             constexpr int pieces = decltype(pieces_c)::value;
@@ -381,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
             }
         };
-        if (d.epilogue == 1) store_rows(std::integral_constant<int, OC / 16>{});
+        if (e_geglu) store_rows(std::integral_constant<int, OC / 16>{});
         else store_rows(std::integral_constant<int, OC / 8>{});
         DC_STAMP_AT(3);
         return;
@@ -447,19 +482,46 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
     }
 }
 
-template <int TM, int TN, int NST, bool A_REG = false>
-int launch_gemm(const dc_conv_desc& d, hipStream_t st)
+template <int TM, int TN, int NST, bool A_REG, int EPI>
+int launch_gemm_e(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
     const int M = d.N * d.Ho * d.Wo;
     const int nblk = dc_cdiv(M, BM) * dc_cdiv(d.Cout, BN);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
     const size_t lds = (size_t)NST * (BM + BN) * 128;
-    auto kern = gemm_dma_kernel<TM, TN, NST, A_REG>;
+    auto kern = gemm_dma_kernel<TM, TN, NST, A_REG, EPI>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);
     return dc_launch_status();
+}
+
+// epilogue mode of a descriptor (see the kernel's EPI comment); 0 = the generic run-time-flag epilogue
+int epi_mode(const dc_conv_desc& d)
+{
+    if (!DC_EPI_SPECIALIZE) return 0;
+    if (d.out_f32 || d.splitk > 1 || d.row_add || d.act) return 0;
+    if (d.epilogue == 1) return (d.residual || d.stats_out || d.gn_part_out) ? 0 : (d.ln_stats ? 5 : 4);
+    if (d.ln_stats) return (d.residual || d.stats_out || d.gn_part_out) ? 0 : 3;
+    return d.residual ? 2 : 1;
+}
+
+// PROD: the four tile shapes the dispatcher uses get every specialised epilogue; developer-knob shapes only the generic one
+template <int TM, int TN, int NST, bool A_REG = false, bool PROD = false>
+int launch_gemm(const dc_conv_desc& d, hipStream_t st)
+{
+    if constexpr (PROD) {
+        switch (epi_mode(d)) {
+            case 1: return launch_gemm_e<TM, TN, NST, A_REG, 1>(d, st);
+            case 2: return launch_gemm_e<TM, TN, NST, A_REG, 2>(d, st);
+            case 3: return launch_gemm_e<TM, TN, NST, A_REG, 3>(d, st);
+            case 4: return launch_gemm_e<TM, TN, NST, A_REG, 4>(d, st);
+            case 5: return launch_gemm_e<TM, TN, NST, A_REG, 5>(d, st);
+            default: break;
+        }
+    }
+    return launch_gemm_e<TM, TN, NST, A_REG, 0>(d, st);
 }
 
 }  // namespace
@@ -476,11 +538,14 @@ int dc_gemm_dma_supported(const dc_conv_desc& d)
     return d.ksize == 1 && d.gn_ab == nullptr;
 }
 
+int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);
+
 int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.Ho * d.Wo;
     // the folded LayerNorm and the row statistics live in the staged (bf16, unsplit) epilogue only
-    if ((d.ln_stats || d.stats_out) && (d.out_f32 || d.splitk > 1)) return DC_ERR_INVALID;
+    if ((d.ln_stats || d.stats_out || d.gn_part_out) && (d.out_f32 || d.splitk > 1)) return DC_ERR_INVALID;
+    if (d.gn_part_out && dc_gemm_dma_gn_chunks(d) == 0) return DC_ERR_INVALID;
     if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;
     if (d.stats_out && d.epilogue != 0) return DC_ERR_INVALID;
     const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
@@ -498,6 +563,19 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     if (hybrid) return n160 ? launch_gemm<2, 5, 2, true>(d, st) : launch_gemm<2, 4, 2, true>(d, st);
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
     if (force_nst == 3 && big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
-    if (big >= 256) return n160 ? launch_gemm<4, 5, 2>(d, st) : launch_gemm<4, 4, 2>(d, st);
-    return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
+    if (big >= 256) return n160 ? launch_gemm<4, 5, 2, false, true>(d, st) : launch_gemm<4, 4, 2, false, true>(d, st);
+    return n160 ? launch_gemm<2, 5, 2, false, true>(d, st) : launch_gemm<2, 4, 3, false, true>(d, st);
+}
+
+// gn_part_out chunks per sample of this launch (0: not available)
+int dc_gemm_dma_gn_chunks(const dc_conv_desc& d)
+{
+    if (d.out_f32 || d.splitk > 1 || d.epilogue != 0 || d.ln_stats) return 0;
+    const long long M = (long long)d.N * d.Ho * d.Wo;
+    const int bn = (d.Cout % 160 == 0) ? 160 : 128;
+    const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn);
+    const int bm = big >= 256 ? 128 : 64;
+    const long long hw = (long long)d.Ho * d.Wo;
+    if (hw % bm) return 0;                                  // a row tile would straddle two samples
+    return (int)(hw / bm) * 2;
 }

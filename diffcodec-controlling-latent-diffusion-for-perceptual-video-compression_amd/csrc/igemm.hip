@@ -20,6 +20,8 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st);
 // gemm_dma.hip: LDS-DMA pipelined GEMM for 1x1 convs / linears without a load-side transform
 int dc_gemm_dma_supported(const dc_conv_desc& d);
 int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st);
+int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);
+int dc_conv3x3_tile_gn_chunks(const dc_conv_desc& d);
 
 namespace {
 
@@ -360,6 +362,14 @@ int launch_cfg(const dc_conv_desc& d, hipStream_t st)
 
 }  // namespace
 
+extern "C" int dc_conv_gn_part_chunks(const dc_conv_desc* dp)
+{
+    if (!dp || dp->splitk > 1) return 0;
+    if (dc_gemm_dma_supported(*dp)) return dc_gemm_dma_gn_chunks(*dp);
+    if (dc_conv3x3_tile_supported(*dp)) return dc_conv3x3_tile_gn_chunks(*dp);
+    return 0;                                               // gather GEMM (strided / GN-on-load 1x1): no statistics epilogue
+}
+
 extern "C" long long dc_conv_igemm_ws_bytes(const dc_conv_desc* d)
 {
     if (!d || d->splitk <= 1) return 0;
@@ -413,6 +423,7 @@ extern "C" int dc_conv_igemm_bf16(const dc_conv_desc* dp, void* stream)
     const int bn = n160 ? 160 : 128;
     const long long big_tiles = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * d.splitk;
     if ((d.ln_stats || d.stats_out) && !dc_gemm_dma_supported(d)) return DC_ERR_INVALID;   // LDS-DMA GEMM epilogue only
+    if (d.gn_part_out && dc_conv_gn_part_chunks(&d) == 0) return DC_ERR_INVALID;
     int rc;
     if (dc_gemm_dma_supported(d)) rc = dc_gemm_dma_launch(d, st);
     else if (dc_conv3x3_tile_supported(d)) rc = dc_conv3x3_tile_launch(d, st);

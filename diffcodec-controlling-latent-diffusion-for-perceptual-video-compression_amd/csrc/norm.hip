@@ -27,17 +27,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
             float s[8], ss[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-            for (long long p = p_begin + pl; p < p_end; p += ppb) {
-                const u32x4 raw = *(const u32x4*)(x + ((long long)n * HW + p) * C + v * 8);
+            for (long long p0 = p_begin + pl; p0 < p_end; p0 += 4LL * ppb) {      // four 16-byte loads in flight per thread
+                u32x4 raw[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = __uint_as_float(raw[j] << 16);
-                    const float hi = __uint_as_float(raw[j] & 0xffff0000u);
-                    s[2 * j] += lo;
-                    ss[2 * j] += lo * lo;
-                    s[2 * j + 1] += hi;
-                    ss[2 * j + 1] += hi * hi;
+                for (int u = 0; u < 4; ++u) {
+                    const long long p = p0 + (long long)u * ppb;
+                    raw[u] = p < p_end ? *(const u32x4*)(x + ((long long)n * HW + p) * C + v * 8) : u32x4{0u, 0u, 0u, 0u};
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = __uint_as_float(raw[u][j] << 16);
+                        const float hi = __uint_as_float(raw[u][j] & 0xffff0000u);
+                        s[2 * j] += lo;
+                        ss[2 * j] += lo * lo;
+                        s[2 * j + 1] += hi;
+                        ss[2 * j + 1] += hi * hi;
+                    }
             }
             float* r = red + ((long long)pl * C + v * 8) * 2;
 #pragma unroll
@@ -158,34 +165,59 @@ __global__ __launch_bounds__(256) void gn_direct_kernel(const bf16_t* __restrict
     }
 }
 
+// y = (x*a+b) [SiLU] of cat[x1,x2].  grid = (pixel chunks, N); a thread owns one 8-channel vector column of one sample (its
+// 16 scale/shift floats stay in registers) and walks the chunk's pixels four at a time, so four 16-byte loads are in flight
+// per thread and the only per-pixel work is the arithmetic: no index divisions, no re-reads of the affine.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, int C1,
                                                        const bf16_t* __restrict__ x2, int C2,
                                                        const float* __restrict__ ab, bf16_t* __restrict__ y,
-                                                       long long HW, long long total_vec, int silu)
+                                                       long long HW, int pix_per_block, int silu)
 {
     const int C = C1 + C2;
     const int nv = C >> 3;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long long)gridDim.x * 256) {
-        const long long pix = i / nv;
-        const int c = (int)(i - pix * nv) * 8;
-        const int n = (int)(pix / HW);
-        const bf16_t* src = c < C1 ? x1 + pix * C1 + c : x2 + pix * C2 + (c - C1);
-        const u32x4 raw = *(const u32x4*)src;
+    const int n = blockIdx.y;
+    const long long p_begin = (long long)blockIdx.x * pix_per_block;
+    const long long p_end = min(HW, p_begin + pix_per_block);
+    const int tpp = min(nv, 256);                  // threads per pixel
+    const int ppb = 256 / tpp;                     // pixels in flight per trip
+    const int vl = threadIdx.x % tpp, pl = threadIdx.x / tpp;
+    if (pl >= ppb) return;
+    for (int v = vl; v < nv; v += tpp) {
+        const int c = v * 8;
+        f32x4 g[4];
         const float* abp = ab + ((long long)n * C + c) * 2;
-        uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 g = *(const f32x4*)(abp + 4 * j);
-            float lo = __uint_as_float(raw[j] << 16) * g[0] + g[1];
-            float hi = __uint_as_float(raw[j] & 0xffff0000u) * g[2] + g[3];
-            if (silu) {
-                lo = dc_silu(lo);
-                hi = dc_silu(hi);
+        for (int j = 0; j < 4; ++j) g[j] = *(const f32x4*)(abp + 4 * j);
+        const bool first = c < C1;
+        const bf16_t* src = first ? x1 + (long long)n * HW * C1 + c : x2 + (long long)n * HW * C2 + (c - C1);
+        const int cs = first ? C1 : C2;
+        bf16_t* dst = y + (long long)n * HW * C + c;
+        for (long long p0 = p_begin + pl; p0 < p_end; p0 += 4LL * ppb) {
+            u32x4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long p = p0 + (long long)u * ppb;
+                if (p < p_end) raw[u] = *(const u32x4*)(src + p * cs);
             }
-            bf16x2 p = {(bf16_t)lo, (bf16_t)hi};
-            o[j] = *(uint32_t*)&p;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long p = p0 + (long long)u * ppb;
+                if (p >= p_end) break;
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float lo = __uint_as_float(raw[u][j] << 16) * g[j][0] + g[j][1];
+                    float hi = __uint_as_float(raw[u][j] & 0xffff0000u) * g[j][2] + g[j][3];
+                    if (silu) {
+                        lo = dc_silu(lo);
+                        hi = dc_silu(hi);
+                    }
+                    bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
+                    o[j] = *(uint32_t*)&pk;
+                }
+                *(u32x4*)(dst + p * C) = u32x4{o[0], o[1], o[2], o[3]};
+            }
         }
-        *(u32x4*)(y + pix * C + c) = u32x4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -325,10 +357,15 @@ extern "C" int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int
 {
     const int C = C1 + C2;
     if (!x1 || !ab || !y || N <= 0 || HW <= 0 || (C1 & 7) || (C2 & 7) || (C2 && !x2)) return DC_ERR_INVALID;
-    const long long total_vec = (long long)N * HW * (C >> 3);
-    const int grid = (int)min((long long)4096, (total_vec + 255) / 256);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x1, C1,
-                       (const bf16_t*)x2, C2, ab, (bf16_t*)y, HW, total_vec, silu);
+    const int nv = C >> 3, tpp = nv < 256 ? nv : 256, ppb = 256 / tpp;
+    // >= 16 pixels per pixel-lane and workgroup (four trips of four), at most ~4096 workgroups in all
+    long long chunks = HW / (16LL * ppb);
+    const long long cap = 4096 / N > 0 ? 4096 / N : 1;
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
+    const int pix_per_block = (int)((HW + chunks - 1) / chunks);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)dc_cdiv(HW, pix_per_block), N), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x1, C1, (const bf16_t*)x2, C2, ab, (bf16_t*)y, HW, pix_per_block, silu);
     return dc_launch_status();
 }
 

@@ -21,7 +21,7 @@ class ConvDesc(ctypes.Structure):
         ("ksize", i32), ("stride", i32), ("pad", i32), ("upsample", i32), ("Ho", i32), ("Wo", i32),
         ("gn_silu", i32), ("epilogue", i32), ("out_f32", i32), ("out_scale", f32), ("splitk", i32), ("gn_batch", i32),
         ("act", i32), ("row_add_stride", i64),
-        ("ln_stats", vp), ("ln_colsum", vp), ("stats_out", vp),
+        ("ln_stats", vp), ("ln_colsum", vp), ("stats_out", vp), ("gn_part_out", vp),
     ]
 
 
@@ -41,6 +41,7 @@ SIGNATURES = {
     "dc_conv_igemm_bf16": [POINTER(ConvDesc), vp],
     "dc_conv_igemm_ws_bytes": [POINTER(ConvDesc)],
     "dc_gemm_row_stats_parts": [i32],
+    "dc_conv_gn_part_chunks": [POINTER(ConvDesc)],
     "dc_row_stats_bf16": [vp, vp, i64, i32, vp],
     "dc_ln_finalize": [vp, vp, i64, i32, i32, f32, vp],
     "dc_conv_small_cin_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],

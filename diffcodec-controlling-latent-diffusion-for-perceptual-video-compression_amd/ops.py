@@ -21,6 +21,8 @@ def _meta(family, shape, flops, nbytes):
 
 
 GN_DIRECT_MAX_PIXELS = int(os.environ.get("DC_GN_DIRECT_MAX_PIXELS", "256"))   # maps up to 16x16: one-launch GroupNorm statistics
+# GroupNorm statistics emitted by the producing conv / GEMM epilogue instead of a read pass (DC_GN_EPILOGUE=0: A/B switch)
+GN_EPILOGUE_STATS = os.environ.get("DC_GN_EPILOGUE", "1") != "0"
 
 
 def _stream():
@@ -154,12 +156,16 @@ def ln_finalize(partials, c, eps):
 
 
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
-         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None, ln_stats=None, stats_out=None):
+         upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None, ln_stats=None, stats_out=None,
+         gn_part=False):
     """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`.  `out`: optional preallocated
     contiguous destination (e.g. one batch half of a larger buffer) on the igemm path.
     ln_stats: (mean, rstd) [M, 2] of the rows of x1 (`ln_finalize`) for a `pc` built with ln=(gamma, beta, eps): LayerNorm folded
     into this linear.
-    stats_out: fp32 [M, row_stats_parts(cout), 2] to receive the row statistics of the OUTPUT (the next block's ln_stats)."""
+    stats_out: fp32 [M, row_stats_parts(cout), 2] to receive the row statistics of the OUTPUT (the next block's ln_stats).
+    gn_part: ask the epilogue for the GroupNorm partial sums of the OUTPUT (dc_conv_desc.gn_part_out); when the launch can
+    emit them the returned tensor carries them as `.gn_part` ([chunks, N, Cout, 2] fp32) and `group_norm_ab` skips its read
+    pass over the tensor; otherwise the request is ignored and `group_norm_ab` measures the tensor as before."""
     _chk(x1, BF16, "x1")
     n, h, w, c1 = x1.shape
     c2 = 0
@@ -228,7 +234,13 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
                  Ho=ho, Wo=wo, gn_silu=int(gn_silu), epilogue=1 if pc.geglu else 0, out_f32=int(out_f32),
                  out_scale=float(out_scale), splitk=int(splitk), gn_batch=0 if gn_ab is None else gn_ab.shape[0],
                  act=int(act), row_add_stride=int(ras), ln_stats=_ptr(ln_stats), ln_colsum=_ptr(pc.colsum if ln_stats is not None else None),
-                 stats_out=_ptr(stats_out))
+                 stats_out=_ptr(stats_out), gn_part_out=0)
+    part = None
+    if gn_part and GN_EPILOGUE_STATS and not out_f32 and not pc.geglu and splitk == 1 and ln_stats is None:
+        chunks = lib.load().dc_conv_gn_part_chunks(d)
+        if chunks > 0:
+            part = torch.empty((chunks, n, pc.cout, 2), device=x1.device, dtype=F32)
+            d.gn_part_out = part.data_ptr()
     meta = None
     if lib.TIMER is not None:
         kk = pc.cin * k * k
@@ -243,6 +255,8 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         meta = _meta(fam, f"{k}x{k} s{stride} up{int(upsample)} M={m} N={pc.cout} K={kk} gn={int(gn_ab is not None)} geglu={int(pc.geglu)} "
                           f"ln={int(ln_stats is not None)} splitk={splitk}", 2.0 * m * pc.cout * kk, nbytes)
     lib.call("dc_conv_igemm_bf16", d, _stream(), meta=meta)
+    if part is not None:
+        out.gn_part = part
     return out
 
 
@@ -307,6 +321,13 @@ def group_norm_ab(x, gamma, beta, groups, eps, x2=None):
     n, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (n * c)
     c2 = 0 if x2 is None else x2.shape[-1]
+    p1 = getattr(x, "gn_part", None)
+    p2 = None if x2 is None else getattr(x2, "gn_part", None)
+    if p1 is not None and (x2 is None or p2 is not None):        # the producers' epilogues already measured the tensors
+        return gn_finalize(p1, gamma, beta, groups, hw, eps, p2)
+    if hw > GN_DIRECT_MAX_PIXELS and (p1 is not None or p2 is not None):
+        return gn_finalize(p1 if p1 is not None else gn_stats(x), gamma, beta, groups, hw, eps,
+                           None if x2 is None else (p2 if p2 is not None else gn_stats(x2)))
     if hw <= GN_DIRECT_MAX_PIXELS and (c + c2) % groups == 0 and ((c + c2) // groups) % 2 == 0 and c % 2 == 0 and c2 % 2 == 0:
         _chk(x, BF16, "x")
         if x2 is not None:

@@ -107,14 +107,14 @@ class HipUNet2DConditionModel:
             assert down_res is None and mid_res is None
             for feats, _, zero, _, scale in controls:
                 assert len(feats) == len(res) == len(zero)
-                res = [ops.conv(f, z, out_scale=scale, residual=r) for f, z, r in zip(feats, zero, res)]
+                res = [ops.conv(f, z, out_scale=scale, residual=r, gn_part=True) for f, z, r in zip(feats, zero, res)]
         elif down_res is not None:
             assert len(down_res) == len(res)
             res = [ops.add_bf16(a, b) for a, b in zip(res, down_res)]          # pipeline.py:364 residual injection
         sample = enc.run_mid(sample, temb)
         if controls:
             for _, mid_feat, _, zero_mid, scale in controls:
-                sample = ops.conv(mid_feat, zero_mid, out_scale=scale, residual=sample)
+                sample = ops.conv(mid_feat, zero_mid, out_scale=scale, residual=sample, gn_part=True)
         elif mid_res is not None:
             sample = ops.add_bf16(sample, mid_res)
         for bi, blk in enumerate(self.up):
@@ -127,7 +127,7 @@ class HipUNet2DConditionModel:
                 if a is not None:
                     sample = a(sample)
             if blk["up"] is not None:
-                sample = ops.conv(sample, blk["up"], upsample=True)            # nearest-2x fused into the conv load
+                sample = ops.conv(sample, blk["up"], upsample=True, gn_part=True)   # nearest-2x fused into the conv load
         ab = ops.group_norm_ab(sample, self.norm_out[0], self.norm_out[1], self.cfg["groups"], 1e-5)
         return ops.conv(sample, self.conv_out, gn_ab=ab, gn_silu=True, out_f32=True)
 

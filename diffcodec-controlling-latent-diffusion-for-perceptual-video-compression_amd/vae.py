@@ -118,7 +118,7 @@ class HipAutoencoderKL:
             for r in blk["resnets"]:
                 x = r(x)
             if blk["up"] is not None:
-                x = ops.conv(x, blk["up"], upsample=True)
+                x = ops.conv(x, blk["up"], upsample=True, gn_part=True)
         ab = ops.group_norm_ab(x, self.d_norm[0], self.d_norm[1], self.cfg["groups"], 1e-6)
         return ops.conv(x, self.d_conv_out, gn_ab=ab, gn_silu=True, out_f32=True)[..., : self.d_out_channels]
 

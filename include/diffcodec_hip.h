@@ -104,12 +104,20 @@ typedef struct dc_conv_desc {
     const float* ln_stats;  /* consumer: [M][2] fp32 (mean, rstd) of every input row (dc_ln_finalize), or NULL */
     const float* ln_colsum; /* consumer: [Cout] fp32 sum over k of the (bf16) weight row, required with ln_stats */
     float* stats_out;       /* producer: [M][dc_gemm_row_stats_parts(Cout)][2] partial (sum, sum sq) of every OUTPUT row, or NULL */
+    /* GroupNorm statistics of the OUTPUT from the epilogue that produces it (ResnetBlock2D.norm1/norm2, Transformer2DModel.norm
+     * and FDN read them next): [dc_conv_gn_part_chunks(desc)][N][Cout][2] fp32 per-(pixel tile, sample, channel) partial
+     * (sum, sum of squares) — the operand dc_gn_finalize takes — instead of a separate read pass over the tensor.  NULL = off.
+     * Only the launches for which dc_conv_gn_part_chunks returns > 0 accept it. */
+    float* gn_part_out;
 } dc_conv_desc;
 int dc_conv_igemm_bf16(const dc_conv_desc* desc, void* stream);
 /* Workspace bytes needed for splitk>1 (0 otherwise). */
 long long dc_conv_igemm_ws_bytes(const dc_conv_desc* desc);
 /* Partials per output row that a 1x1 / linear launch with `stats_out` writes (one per wave column slice of the tile grid). */
 int dc_gemm_row_stats_parts(int Cout);
+/* Pixel-tile partials per sample that a launch of `desc` writes to gn_part_out; 0 if that launch cannot emit them (split-K,
+ * GEGLU, fp32 output of a 1x1, kernels without the statistics epilogue, pixel tiles that straddle samples). */
+int dc_conv_gn_part_chunks(const dc_conv_desc* desc);
 /* Row statistics of a bf16 matrix x [M][C] for `ln_stats` when the producing launch cannot emit them (one partial per row):
  * stats [M][1][2] = (sum, sum of squares). */
 int dc_row_stats_bf16(const void* x, float* stats, long long M, int C, void* stream);

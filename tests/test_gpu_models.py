@@ -125,9 +125,9 @@ def test_pipeline_fused_generic_and_graph_agree_with_oracle(small):
         img_h2 = pipe(**kw).images.float().cpu()
     finally:
         pipe.enable_hip_graphs(False)
-    # run-to-run differences come only from fp32 atomic summation order (GN statistics, split-K), amplified by 4 steps
-    assert T.psnr(img_h, img) > 36.0 and T.psnr(img_h2, img) > 36.0
-    assert T.psnr(img_h, ref_img) > 30.0 and T.psnr(img_h2, ref_img) > 30.0
+    # a captured step replays exactly the launches of the eager step: bit-identical frames (the decode is deterministic since
+    # the LDS-ring race of round 1 was fixed; the control pyramid with its atomic splat is cached across these calls)
+    assert torch.equal(img_h, img) and torch.equal(img_h2, img)
 
 
 def test_pipeline_errors_and_batch(small):
@@ -145,7 +145,7 @@ def test_pipeline_errors_and_batch(small):
     # frames are independent units: batch of 2 == two single-frame calls (sharding premise)
     one = pipe(prompt_embeds=pe[1:], negative_prompt_embeds=npe[1:], controlnet_cond=cond[1:], flow_cond=flow[1:], latents=lat[1:],
                num_inference_steps=2, guidance_scale=4.5, output_type="np")
-    assert T.psnr(torch.from_numpy(one.images[0]), torch.from_numpy(out.images[1])) > 38.0
+    assert T.psnr(torch.from_numpy(one.images[0]), torch.from_numpy(out.images[1])) > 45.0    # other M -> other tiling: reassociation only
 
 
 def test_smoke_entry():
@@ -348,8 +348,8 @@ def test_dual_stream_step_equals_single_stream(small):
     finally:
         pipe.enable_hip_graphs(False)
         pipe.enable_dual_stream(False)
-    for x in (a, b, c):
-        assert T.psnr(x, base) > 36.0
+    for x in (a, b, c):                                   # two streams / graph replay reorder nothing inside a stream: same bits
+        assert torch.equal(x, base)
 
 
 def test_cfg_shared_prefix_equals_duplicated_batch(small):
@@ -372,9 +372,10 @@ def test_cfg_shared_prefix_equals_duplicated_batch(small):
             g = pipe(**kw).images.float().cpu()
         finally:
             pipe.enable_hip_graphs(False)
-        # two runs of the SAME settings already differ at 44-48 dB (the splat's atomic arrival order, amplified over the steps:
-        # tools/noise_floor.py), so the bar for a different-but-equivalent schedule sits just below that floor
-        assert T.psnr(a, base) > 38.0 and T.psnr(g, base) > 38.0, (b, T.psnr(a, base), T.psnr(g, base))
+        # not bit-preserving by construction: the shared prefix runs its GEMMs at half the rows, which moves tile / split-K
+        # choices and with them fp32 summation order.  Identical settings are bit-identical (tools/find_nondeterminism.py), so
+        # the bar is the reassociation noise of a 3-step decode, not a run-to-run floor
+        assert T.psnr(a, base) > 45.0 and torch.equal(g, a), (b, T.psnr(a, base), T.psnr(g, base))
 
 
 def test_control_guidance_window_vs_oracle(small):
@@ -396,7 +397,7 @@ def test_control_guidance_window_vs_oracle(small):
         img_h = pipe(**kw).images.float().cpu()
     finally:
         pipe.enable_hip_graphs(False)
-    assert T.psnr(img_h, img) > 38.0                     # run-to-run floor of identical settings is 44-48 dB (tools/noise_floor.py)
+    assert torch.equal(img_h, img)                       # graph replay (two graph keys) == eager, bit for bit
 
 
 def test_multi_step_graphs_equal_single_step_graphs(small):
@@ -415,7 +416,7 @@ def test_multi_step_graphs_equal_single_step_graphs(small):
             b = pipe(**kw, **extra).images.float().cpu()          # second call: pure replay
         finally:
             pipe.enable_hip_graphs(False)
-        assert T.psnr(a, base) > 38.0 and T.psnr(b, base) > 38.0      # run-to-run floor of identical settings: 44-48 dB
+        assert torch.equal(a, base) and torch.equal(b, base)           # k steps per graph replay the same launches: same bits
 
 
 def test_full_size_sd15_vae_decode_and_postprocess():
@@ -677,3 +678,30 @@ def test_full_size_vae_encode_sample_and_latent_init_decode():
                **kw).images.float().cpu()
     ref = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, vcfg, cond, flow, pe, npe, ref_s * vcfg["scaling_factor"], **kw)
     assert T.psnr(img, ref) > 30.0
+
+
+def test_identical_calls_are_bit_identical_and_reuse_the_control_cache(small):
+    """two calls with the same control tensors must not re-enter compute_pyramid (identity cache), and — with the
+    splat therefore out of the picture — every other kernel is deterministic, so the frames are equal bit for bit.  A fresh
+    copy of the controls re-runs the pyramid (atomic splat: last-bit differences allowed there)."""
+    T, pipe, _ = small
+    cond, flow, pe, npe, lat = _inputs(T)
+    cond, flow = cond.to(DEV), flow.to(DEV)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=3, guidance_scale=4.5, controlnet_conditioning_scale=1.7, output_type="pt")
+    cn = pipe.controlnet
+    calls = []
+    orig = cn.compute_pyramid
+    cn.compute_pyramid = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        a = pipe(**kw).images
+        n_first = len(calls)
+        b = pipe(**kw).images
+        c = pipe(**kw).images
+        assert len(calls) == n_first <= 1                      # cached by (pointer, shape, version) of the control tensors
+        assert torch.equal(a, b) and torch.equal(a, c)
+        d = pipe(**dict(kw, controlnet_cond=cond.clone(), flow_cond=flow.clone())).images
+        assert len(calls) == n_first + 1
+        assert T.psnr(d.float().cpu(), a.float().cpu()) > 50.0
+    finally:
+        cn.compute_pyramid = orig

@@ -280,6 +280,33 @@ def test_layer_norm(ops):
         close(out.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,up", [(2, 32, 32, 64, 320, 3, 0), (2, 16, 16, 128, 640, 3, 0), (4, 8, 8, 128, 320, 3, 0),
+                                                (3, 8, 8, 128, 320, 3, 0), (1, 16, 16, 64, 128, 3, 1), (2, 16, 16, 192, 320, 1, 0),
+                                                (2, 64, 64, 64, 160, 1, 0), (2, 8, 8, 128, 320, 1, 0), (3, 4, 4, 128, 320, 1, 0)])
+def test_group_norm_statistics_from_the_producing_epilogue(ops, n, h, w, cin, cout, k, up):
+    """dc_conv_desc.gn_part_out: the conv / GEMM epilogue that writes a tensor also writes its GroupNorm partial sums, and
+    `group_norm_ab` turns them into the same per-(sample, channel) scale / shift as the read pass (gn_stats / gn_direct) over
+    the stored tensor — 8-row, 4-row and two-images-per-tile conv tiles, fused upsample, the LDS-DMA GEMM with a residual;
+    when the rows of one sample do not fill a GEMM row tile (4x4 map), the launch declines and the read pass stays."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV, torch.bfloat16)
+    pc = ops.PackedConv(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k), 0.5 * torch.randn(cout, generator=g), DEV)
+    ho = h * (2 if up else 1)
+    res = torch.randn(n, ho, ho, cout, generator=g).to(DEV, torch.bfloat16)
+    y = ops.conv(x, pc, residual=res, upsample=bool(up), out_scale=1.3, gn_part=True)
+    gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)
+    if not hasattr(y, "gn_part"):                      # only a GEMM row tile that straddles two samples may decline
+        assert k == 1 and (h * w) % 64 != 0
+        return
+    assert y.gn_part.shape[1:] == (n, cout, 2)
+    fused = ops.group_norm_ab(y, gamma, beta, 32, 1e-5)
+    plain = ops.group_norm_ab(y.clone(), gamma, beta, 32, 1e-5)          # the clone carries no partials: read pass
+    # fp32 sums of the values before (epilogue) / after (read pass) the bf16 rounding of y
+    torch.testing.assert_close(fused, plain, rtol=2e-3, atol=2e-3)
+    y0 = ops.conv(x, pc, residual=res, upsample=bool(up), out_scale=1.3)
+    assert torch.equal(y0, y)                                            # asking for statistics does not change the output
+
+
 @pytest.mark.parametrize("c,mean", [(320, 0.3), (640, 2.5), (1280, -1.0)])
 def test_layer_norm_folded_into_linear(ops, c, mean):
     """BasicTransformerBlock.norm1/2/3 -> to_q/k/v | to_q | ff.net.0.proj with the LayerNorm folded into the weights and the
