@@ -17,6 +17,18 @@
 namespace {
 
 constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key MFMA tiles)
+#ifndef DC_ATTN_PRESCALE
+#define DC_ATTN_PRESCALE 1                   // developer A/B switch for the accumulator-initialised softmax (see process_tile)
+#endif
+// Offset-in-the-GEMM online softmax (head dims with a spare zero-padded column: d = 40, 8): the queries are pre-multiplied by
+// scale*log2(e) once per block (fp32 multiply, one bf16 rounding), column D of every K row is 1.0 in LDS and element D of the
+// query fragment holds minus the running offset — so the QK^T MFMA chain itself leaves t = log2e*scale*s - offset, ready for
+// v_exp_f32: no per-score FMA and no accumulator initialisation.  The offset (kept bf16-exact, so the product is exact)
+// follows the running maximum lazily: it moves only when a tile's maximum exceeds it by more than RESCALE_THR
+// (probabilities then reach 2^THR instead of 1, harmless in fp32/bf16 range) or on a block's first tile — the
+// subtract-and-rescale pass is the exception, not the rule.  The d = 40 kernel is VALU-issue-bound (64 exps + 32 converts +
+// 16 max3 per 28 MFMAs and tile): the 32 packed FMAs this removes were ~13 % of its VALU time.
+constexpr float RESCALE_THR = 4.0f;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // V stays row-major [key][d] in LDS (one ds_write_b128 per staged vector); the PV MFMA's A operand (V^T: 4 consecutive
@@ -63,6 +75,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     // Row sums for free: when the head dim leaves a spare zero-padded column (d = 40, 80, 8, 16), V's column D is set to
     // 1.0 in LDS, so O^T row D accumulates sum_k p — the softmax denominator — inside the PV MFMA, already rescaled by
     // the running-max correction.  Saves one v_add_f32 per probability.
+    // spare QK^T column available for the offset; not for the short-context form (two tiles per block: the first-tile anchor
+    // pass costs more than the two tiles of FMAs it saves — measured 74 vs 68 us at 4096 x 77, d = 40)
+    constexpr bool QOFF = DC_ATTN_PRESCALE && (D % 16) != 0 && !SHORT;
+    constexpr int QOFF_KS = D / 16, QOFF_LH = (D % 16) / 8, QOFF_E = (D % 16) % 8;
     constexpr bool ONES = (D % 32) != 0;
     constexpr int ONES_T = D / 32, ONES_R = ((D % 32) & 3) + 4 * ((D % 32) >> 3);
     static_assert(!ONES || ((D % 32) % 8) < 4, "ones row must live in the lower lane half");
@@ -86,8 +102,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     for (int i = tid * 16; i < 2 * BUF; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
     if (ONES) {
         __syncthreads();
-        if (tid < 2 * KV_TILE)
+        if (tid < 2 * KV_TILE) {
             *(unsigned short*)(smem + (tid >> 6) * BUF + K_BYTES + (tid & 63) * V_PITCH + D * 2) = 0x3F80;   // bf16 1.0
+            if (QOFF) *(unsigned short*)(smem + (tid >> 6) * BUF + (tid & 63) * K_PITCH + D * 2) = 0x3F80;   // K column D = 1
+        }
     }
 
     // Q^T fragments: lane holds Q[q0 + 32*u + lq][16*ks + 8*lh .. +7]
@@ -103,7 +121,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 const int qi = qbase + 32 * u + lq;
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (qi < a.Nq && dcol < D) v = *(const u32x4*)(Q + (long long)qi * a.qs + dcol);
-                dst[u][ks] = *(bf16x8*)&v;
+                bf16x8 qv = *(bf16x8*)&v;
+                if (QOFF) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qv[e] = (bf16_t)((float)qv[e] * a.scale_log2e);
+                }
+                dst[u][ks] = qv;
             }
     };
     auto reset_acc = [&]() {
@@ -113,7 +136,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             for (int t = 0; t < NDT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[u][t][r] = 0.f;
-            m_run[u] = -INFINITY;
+            m_run[u] = QOFF ? 0.f : -INFINITY;                 // QOFF: the offset (log2 domain, bf16-exact), set by the first tile
             l_run[u] = 0.f;
         }
     };
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     __syncthreads();
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    auto process_tile = [&](int t) {
+    auto process_tile = [&](int t, bool first) {
         const int buf = t & 1;
         const char* sK = smem + buf * BUF;
         const char* sV = sK + K_BYTES;
@@ -206,6 +229,38 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             {   // exchange with lane ^ 32 on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
                 mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            if (QOFF) {
+                // s already holds t = log2-domain score - offset.  Move the offset only where this tile's maximum runs ahead of it
+                // by more than the threshold (or on the first tile of a block, to anchor it at a real maximum).
+                const float m_next = (float)(bf16_t)(m_run[u] + mloc);       // the new offset, bf16-exact
+                const float delta = (first || mloc > RESCALE_THR) ? m_next - m_run[u] : 0.f;
+                if (__any(delta != 0.f)) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);      // first tile: O and l are still zero
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[u][j][r] -= delta;
+                    if (!ONES) l_run[u] *= alpha;
+#pragma unroll
+                    for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[u][tt][r] *= alpha;
+                    m_run[u] += delta;
+                    if (lh == QOFF_LH) qf[u][QOFF_KS][QOFF_E] = (bf16_t)(-m_run[u]);   // next tiles: the MFMA subtracts it
+                }
+                float lsum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float p0 = __builtin_amdgcn_exp2f(s[u][j][r]), p1 = __builtin_amdgcn_exp2f(s[u][j][r + 1]);
+                        if (!ONES) lsum += p0 + p1;
+                        pf[u][j][r >> 3][r & 7] = (bf16_t)p0;
+                        pf[u][j][r >> 3][(r & 7) + 1] = (bf16_t)p1;
+                    }
+                if (!ONES) l_run[u] += lsum;
+                continue;
             }
             const float m_new = fmaxf(m_run[u], mloc);
             const float mc = m_new * a.scale_log2e;
@@ -317,7 +372,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         for (int t = 0; t < ntiles; ++t) {
             const bool more = t + 1 < ntiles;
             if (more) issue_loads(t + 1);
-            process_tile(t);
+            process_tile(t, t == 0);
             if (more) store_lds((t & 1) ^ 1);
             __syncthreads();
         }
@@ -332,7 +387,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             const bool has_next = pass + 1 < SHORT_PASSES && q0 + 4 * QW < a.Nq;
             bf16x8 qn[QB][ND16];
             if (has_next) fetch_q(q0 + 4 * QW, qn);            // next block's queries fly while this one computes
-            for (int t = 0; t < ntiles; ++t) process_tile(t);
+            for (int t = 0; t < ntiles; ++t) process_tile(t, t == 0);
             store_out();
             if (!has_next) break;
             q0 += 4 * QW;

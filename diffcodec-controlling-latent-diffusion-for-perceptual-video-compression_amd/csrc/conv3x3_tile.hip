@@ -184,7 +184,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         }
     };
     const int last_step = (c_end - c_begin) * 9 - 1;
+#ifndef DC_EXP_NO_DMA
+#define DC_EXP_NO_DMA 0         // developer experiment (wrong results): 1 = weight stages are issued in the prologue only — the
+#endif                          // K loop then runs without any DMA traffic or latency: an upper bound for pipelining changes
     auto issue_b = [&](int step, int slot) {          // step = (cc - c_begin) * 9 + tap ; past-the-end re-reads the last
+        if (DC_EXP_NO_DMA && step >= NSTB - 1) return;
         step = step < last_step ? step : last_step;
         const int cc = c_begin + step / 9, tap = step % 9;
         const long long off = ((long long)tap * Cin + cc * 64) * 2;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     for (int cc = c_begin; cc < c_end; ++cc) {
         const bool more_c = cc + 1 < c_end;
         for (int tap = 0; tap < 9; ++tap, ++step) {
-            dc_ring_sync<NB * (NSTB - 2)>();                     // this wave's pieces of weight stage `step` have landed and its reads of
+            dc_ring_sync<DC_EXP_NO_DMA ? 0 : NB * (NSTB - 2)>(); // this wave's pieces of weight stage `step` have landed and its reads of
                                                                  // step-1 have returned; after the barrier everyone's have: halo image
                                                                  // visible, slot step-1 free
             load_frags(tap, step % NSTB);

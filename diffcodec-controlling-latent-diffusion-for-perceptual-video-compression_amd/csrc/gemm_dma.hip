@@ -136,7 +136,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
             src2[i] = nullptr;
         }
     }
+#ifndef DC_EXP_NO_DMA
+#define DC_EXP_NO_DMA 0         // developer experiment (wrong results): 1 = stages are issued in the prologue only
+#endif
     auto issue_stage = [&](int kt, int slot) {
+        if (DC_EXP_NO_DMA && kt >= kt_begin + NST - 1) return;
         kt = kt < kt_end ? kt : kt_end - 1;           // past-the-end stages re-read the last one (keeps vmcnt counts constant)
         char* base = smem + slot * STAGE;
         if (kt < c1_steps) {                          // first K range (the only one without a channel concat): no per-piece select
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s) issue_stage(kt_begin + s, s);
         for (int k = 0; k < nk; ++k) {
-            dc_ring_sync<NGW * (NST - 2)>();              // this wave's pieces of stage k have landed and its reads of stage k-1 have
+            dc_ring_sync<DC_EXP_NO_DMA ? 0 : NGW * (NST - 2)>();   // this wave's pieces of stage k have landed and its reads of stage k-1 have
                                                           // returned; after the barrier: everyone else's too
             if (k == 0) DC_STAMP_AT(1);
             load_frags(k % NST);
@@ -539,6 +543,10 @@ int dc_gemm_dma_supported(const dc_conv_desc& d)
 }
 
 int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);
+// gemm_wide.hip: the 256-row ping-pong kernel for long-K launches
+int dc_gemm_wide_wanted(const dc_conv_desc& d, int epi);
+int dc_gemm_wide_launch(const dc_conv_desc& d, int epi, hipStream_t st);
+int dc_gemm_wide_gn_chunks(const dc_conv_desc& d);
 
 int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
 {
@@ -546,6 +554,10 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     // the folded LayerNorm and the row statistics live in the staged (bf16, unsplit) epilogue only
     if ((d.ln_stats || d.stats_out || d.gn_part_out) && (d.out_f32 || d.splitk > 1)) return DC_ERR_INVALID;
     if (d.gn_part_out && dc_gemm_dma_gn_chunks(d) == 0) return DC_ERR_INVALID;
+    {
+        const int epi = epi_mode(d);
+        if (dc_gemm_wide_wanted(d, epi)) return dc_gemm_wide_launch(d, epi, st);
+    }
     if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;
     if (d.stats_out && d.epilogue != 0) return DC_ERR_INVALID;
     const bool n160 = (d.Cout % 160 == 0) && d.epilogue == 0;
@@ -571,6 +583,11 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
 int dc_gemm_dma_gn_chunks(const dc_conv_desc& d)
 {
     if (d.out_f32 || d.splitk > 1 || d.epilogue != 0 || d.ln_stats) return 0;
+    {   // the launch decision must be the one dc_gemm_dma_launch takes with gn_part_out set (the host sizes the buffer from here)
+        dc_conv_desc q = d;
+        if (!q.gn_part_out) q.gn_part_out = (float*)(uintptr_t)16;
+        if (dc_gemm_wide_wanted(q, epi_mode(q))) return dc_gemm_wide_gn_chunks(q);
+    }
     const long long M = (long long)d.N * d.Ho * d.Wo;
     const int bn = (d.Cout % 160 == 0) ? 160 : 128;
     const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn);

@@ -353,6 +353,55 @@ def test_layer_norm_folded_into_linear(ops, c, mean):
         ops.linear(t, pc)                               # folded weights without statistics: refused, never silently wrong
 
 
+@pytest.mark.parametrize("m,k,n", [(16384, 640, 1280), (12288, 1280, 640), (8192, 1920, 1280)])
+def test_wide_gemm_long_k_shapes(ops, m, k, n):
+    """Shapes the dispatcher hands to the 256-row ping-pong GEMM (gemm_wide.hip: K >= 640, whole tiles, >= 192 tiles): every
+    specialised epilogue against fp32 torch on the same bf16 operands — bias; bias + scale + residual with the LayerNorm row
+    statistics and the GroupNorm partials of the output; folded LayerNorm; GEGLU; folded LayerNorm + GEGLU; a channel-concat
+    input (two K ranges).  Each launch twice: the ring / barrier protocol must give the same bits."""
+    g = torch.Generator().manual_seed(40)
+    x = bf(torch.randn(1, m, k, generator=g))
+    w = bf(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g) * 0.1
+    xd = x.to(DEV, torch.bfloat16)
+    pc = ops.PackedConv(w, b, DEV)
+    ref = F.linear(x, w, b)
+    out = ops.linear(xd, pc)
+    close(out.float().cpu(), ref)
+    assert torch.equal(out, ops.linear(xd, pc))
+    # residual + scale + statistics (4-D call: per-sample GroupNorm partials)
+    hw = 4096 if m % 4096 == 0 else 2048
+    res = bf(torch.randn(1, m, n, generator=g))
+    st = torch.full((m, ops.row_stats_parts(n), 2), float("nan"), device=DEV)
+    y = ops.conv(xd.reshape(m // hw, hw // 64, 64, k), pc, residual=res.to(DEV, torch.bfloat16).reshape(m // hw, hw // 64, 64, n),
+                 out_scale=0.7, stats_out=st, gn_part=True)
+    ref2 = 0.7 * ref + res
+    close(y.reshape(1, m, n).float().cpu(), ref2, rtol=3e-2, atol=3e-2)
+    yf = y.reshape(m, n).float().cpu()
+    close(st.sum(1)[:, 0].cpu(), yf.sum(-1), rtol=2e-3, atol=0.5)
+    close(st.sum(1)[:, 1].cpu(), (yf ** 2).sum(-1), rtol=5e-3, atol=1.0)
+    gamma, beta = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV), (0.1 * torch.randn(n, generator=g)).to(DEV)
+    close(ops.group_norm_ab(y, gamma, beta, 32, 1e-5), ops.group_norm_ab(y.clone(), gamma, beta, 32, 1e-5), rtol=2e-3, atol=2e-3)
+    # folded LayerNorm, plain and GEGLU
+    lg, lb = 1 + 0.2 * torch.randn(k, generator=g), 0.2 * torch.randn(k, generator=g)
+    ln = F.layer_norm(x, (k,), lg, lb, 1e-5)
+    mr = ops.ln_finalize(ops.row_stats(xd), k, 1e-5)
+    close(ops.linear(xd, ops.PackedConv(w, None, DEV, ln=(lg, lb, 1e-5)), ln_stats=mr).float().cpu(), F.linear(ln, w), rtol=3e-2, atol=3e-2)
+    w1 = bf(torch.randn(2 * n, k, generator=g) / math.sqrt(k))
+    b1 = torch.randn(2 * n, generator=g) * 0.1
+    hid, gate = F.linear(x, w1, b1).chunk(2, -1)
+    o = ops.linear(xd, ops.PackedConv(w1, b1, DEV, geglu=True))
+    close(o.float().cpu(), hid * F.gelu(gate), rtol=3e-2, atol=3e-2)
+    assert torch.equal(o, ops.linear(xd, ops.PackedConv(w1, b1, DEV, geglu=True)))
+    hid, gate = F.linear(ln, w1, b1).chunk(2, -1)
+    close(ops.linear(xd, ops.PackedConv(w1, b1, DEV, geglu=True, ln=(lg, lb, 1e-5)), ln_stats=mr).float().cpu(), hid * F.gelu(gate),
+          rtol=3e-2, atol=3e-2)
+    # channel concat: cat[x[..., :k1], x[..., k1:]] read in place
+    k1 = 320 if k > 640 else 256
+    xa, xb = xd[..., :k1].contiguous().reshape(1, 1, m, k1), xd[..., k1:].contiguous().reshape(1, 1, m, k - k1)
+    close(ops.conv(xa, pc, x2=xb).reshape(1, m, n).float().cpu(), ref)
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("b,heads,nq,nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
                                              (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),

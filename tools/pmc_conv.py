@@ -11,4 +11,18 @@ for (h, c, cout, k) in [(64, 320, 320, 3), (32, 640, 640, 3), (64, 320, 320, 1)]
     for _ in range(5):
         y = ops.conv(x, pc)
     torch.cuda.synchronize()
-    print(f"shape n={n} {h}x{h} {c}->{cout} k{k}: algorithmic bytes = {x.numel()*2 + pc.w.numel()*2 + y.numel()*2}")
+    print(f"shape n={n} {h}x{h} {c}->{cout} k{k}: algorithmic bytes = {x.numel()*2 + pc.w.numel()*2 + y.numel()*2} M={n*h*h} grid_threads={'?'}")
+# flash attention, d = 40, 64x64 tokens (the third family by time)
+q = torch.randn(n, 4096, 960, generator=g).to("cuda", torch.bfloat16)
+for _ in range(3):
+    o = ops.attention(q[..., :320], q[..., 320:640], q[..., 640:], 8)
+torch.cuda.synchronize()
+print(f"shape attention B={n} H=8 N=4096 d=40: algorithmic bytes = {q.numel()*2 + o.numel()*2}")
+# GroupNorm apply (+SiLU) and statistics, 64x64x640: the HBM-bound passes
+xg = torch.randn(n, 64, 64, 640, generator=g).to("cuda", torch.bfloat16)
+ab = torch.randn(n, 640, 2, generator=g).to("cuda")
+for _ in range(3):
+    yg = ops.gn_apply(xg, ab, silu=True)
+    st = ops.gn_stats(xg)
+torch.cuda.synchronize()
+print(f"shape gn_apply N={n} 64x64x640: algorithmic bytes = {xg.numel()*4}; gn_stats: {xg.numel()*2}")
