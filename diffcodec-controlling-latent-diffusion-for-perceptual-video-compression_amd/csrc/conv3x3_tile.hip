@@ -20,18 +20,37 @@
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
 #include <cstdlib>
+#include <utility>
 
 #ifndef DC_EPI_SPECIALIZE
 #define DC_EPI_SPECIALIZE 1     // developer A/B switch: 0 = every launch takes the generic run-time-flag epilogue
 #endif
+#ifndef DC_CONV_FAST
+#define DC_CONV_FAST 1          // developer A/B switch: 0 = plain maps also take the XOR-swizzled, whole-step K loop
+#endif
 #ifndef DC_CONV_PIPE
 #define DC_CONV_PIPE 1          // developer A/B switch for the scheduled K-step (see `mfma_frags`)
+#endif
+
+// Developer-only phase stamps (tools/conv_stamp.py builds this file with -DDC_STAMP into a scratch .so): s_memtime sums of
+// the K loop's barrier waits, its fragment-read + MFMA phases and the halo swaps, plus entry / loop / exit times, written to
+// the (otherwise unused) split-K workspace.  Never defined in the product build.
+#ifdef DC_STAMP
+#define DC_NOW(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#else
+#define DC_NOW(t) (void)0
 #endif
 
 namespace {
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int... I, class F>
+__device__ __forceinline__ void dc_static_for(std::integer_sequence<int, I...>, F&& f)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
@@ -42,9 +61,17 @@ __device__ __forceinline__ void wait_vmcnt()
 // EPI: epilogue specialisation (same reasoning as gemm_dma.hip): 0 = generic run-time flags (split-K slabs, fp32 output,
 // activation), 1 = bias (+ time-embedding row) -> bf16, 2 = the same + scaled residual add.  gn_part_out stays a run-time,
 // workgroup-uniform test outside the loops.
-template <int TM, int TN, bool GN, int NSTB, int EPI>
+//
+// FAST (plain maps at least 16 wide, no fused upsample; NSTB == 2): the halo image uses 160-byte pixel rows WITHOUT the XOR
+// swizzle (16 consecutive pixels at one channel chunk are still bank-conflict-free), so a tap is an immediate offset from one
+// per-lane base address and the nine taps are unrolled with no address arithmetic left in the K loop; and the fragment reads
+// are software-pipelined ACROSS K-steps in two half-steps (32 channels each): while the MFMAs of one half run, the reads of
+// the next half are in flight, with the workgroup barrier in the middle of the step (stage k+1 must be visible before its
+// first half is read).  A wave then never sits at the top of a step waiting for 18 reads with no MFMA to issue.
+template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
+    static_assert(!FAST || NSTB == 2, "the half-step pipeline is written for the two-slot weight ring");
     constexpr bool GENERIC = EPI == 0;
     const bool e_split = GENERIC && d.splitk > 1;
     const bool e_res = GENERIC ? (d.residual != nullptr && d.splitk <= 1) : EPI == 2;
@@ -53,10 +80,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * TM;                       // output rows per tile (tile is TH x 16 pixels)
     constexpr int BN = WN * TN * 16;
-    constexpr int HALO_MAX = TM == 4 ? 200 : (TH + 2) * 18;   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
+    constexpr int HALO_MAX = (TM == 4 && !FAST) ? 200 : (TH + 2) * 18;   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
     constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
-    constexpr int H_BYTES = HALO_MAX * 128;
+    constexpr int HP = FAST ? 160 : 128;              // halo pixel-row pitch (bytes)
+    constexpr int H_BYTES = HALO_MAX * HP;
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sH = smem;
@@ -71,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     const int Cin = d.C1 + d.C2;
     const int nchunks = Cin >> 6;
     // narrow maps (Wo == 8): the 16 lanes of an MFMA row cover 2 image rows of 8 pixels (sh = 1)
-    const int sh = d.Wo < 16 ? 1 : 0;
+    const int sh = FAST ? 0 : (d.Wo < 16 ? 1 : 0);
     const int TW = 16 >> sh;
     // dual: 8x8 maps with the 8-row tile shape — one tile = TWO whole images (wave row wm = image), so the weight tile
     // streamed per K-step serves 128 pixels instead of 64 at the weight-bound 8x8 layers
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
 
     // ---- halo geometry (input coordinates).  upsample: output tile lives on the 2x grid, halo on the input grid
-    const int up = d.upsample;
+    const int up = FAST ? 0 : d.upsample;
     const int HWd = up ? 10 : TW + 2;
     const int HHt = up ? TH / 2 + 2 : (dual ? 10 : (TH << sh) + 2);
     const int himg = HHt * HWd;                                 // halo pixels per image (dual: two images back to back)
@@ -124,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             pix = (iy >= 0 && iy < d.H && ix >= 0 && ix < d.W) ? ((n_img0 + im) * d.H + iy) * d.W + ix : -1;
         }
         h_pix[i] = pix;
-        h_lds[i] = hp * 128 + ((q ^ (hp & 7)) << 4);
+        h_lds[i] = FAST ? hp * HP + (q << 4) : hp * 128 + ((q ^ (hp & 7)) << 4);
     }
     // weight-tile DMA: piece g (8 rows) of a stage; lane -> row 8g + (lane>>3), LDS slot lane&7 = source chunk ^ (row&7)
     const char* b_src[NB];
@@ -150,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
         for (int i = 0; i < NHU; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (h_pix[i] >= 0) v = *(const u32x4*)(src + (long long)h_pix[i] * cs + co);
+            if (FAST) v = *(const u32x4*)(src + (long long)max(h_pix[i], 0) * cs + co);   // always NHU loads (counted vmcnt)
+            else if (h_pix[i] >= 0) v = *(const u32x4*)(src + (long long)h_pix[i] * cs + co);
             rh[i] = v;
         }
     };
@@ -165,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         for (int i = 0; i < NHU; ++i) {
             if (h_pix[i] == -2) continue;
             u32x4 v = rh[i];
+            if (FAST && h_pix[i] < 0) v = u32x4{0u, 0u, 0u, 0u};
             if (GN && h_pix[i] >= 0) {
                 uint32_t o[4];
 #pragma unroll
@@ -191,6 +221,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         if (DC_EXP_NO_DMA && step >= NSTB - 1) return;
         step = step < last_step ? step : last_step;
         const int cc = c_begin + step / 9, tap = step % 9;
+        const long long off = ((long long)tap * Cin + cc * 64) * 2;
+        char* base = sB0 + slot * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + off), (lptr_t)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+    };
+
+    auto issue_b_at = [&](int cc, int tap, int slot) {   // the same with (slice, tap) known: no division in the unrolled K loop
+        if (DC_EXP_NO_DMA) return;
+        const bool past = cc >= c_end;
+        cc = past ? c_end - 1 : cc;
+        tap = past ? 8 : tap;
         const long long off = ((long long)tap * Cin + cc * 64) * 2;
         char* base = sB0 + slot * B_BYTES;
 #pragma unroll
@@ -231,6 +273,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         }
     };
     auto mfma_frags = [&]() {
+#ifdef DC_EXP_PRIO
+        __builtin_amdgcn_s_setprio(DC_EXP_PRIO);
+#endif
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -238,6 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s][tn], xf[s][tm], acc[tn][tm], 0, 0, 0);
+#ifdef DC_EXP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (DC_CONV_PIPE) {
             constexpr int NMF = 2 * TN * TM;
             constexpr int PER = NMF / (NB + 1) > 0 ? NMF / (NB + 1) : 1;
@@ -251,6 +299,117 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         }
     };
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ta = 0, tb = 0, tc = 0, s_sync = 0, s_work = 0, s_halo = 0;
+    DC_NOW(ts0);
+    if constexpr (FAST) {
+        // ---- FAST main loop (see the kernel comment): half-step pipeline, taps unrolled, mid-step barrier
+        const int a_lane = ((wm * TM) * 18 + fr) * HP + (fq << 4);           // this lane's halo byte offset at tap (0,0), tm 0, half 0
+        int b_lane[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) b_lane[s] = H_BYTES + ((wn * TN) * 16 + fr) * 128 + (((4 * s + fq) ^ (fr & 7)) << 4);
+        bf16x8 xa[2][TM], wb[2][TN];
+        auto rd_half = [&](int tap, int s, int slot_off) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) xa[s][tm] = *(const bf16x8*)(sH + a_lane + ((tm + ky) * 18 + kx) * HP + s * 64);
+            const char* bp = smem + b_lane[s] + slot_off;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) wb[s][tn] = *(const bf16x8*)(bp + tn * 2048);
+        };
+        auto mfma_half = [&](int s) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s][tn], xa[s][tm], acc[tn][tm], 0, 0, 0);
+        };
+        constexpr int NMF = TN * TM, NRD = TN + TM;
+        issue_halo(c_begin);
+        issue_b(0, 0);
+        store_halo(c_begin);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rd_half(0, 0, 0);
+        issue_b(1, 1);
+        int step = 0;
+        DC_NOW(ts1);
+        for (int cc = c_begin; cc < c_end; ++cc) {
+            const bool more_c = cc + 1 < c_end;
+            dc_static_for(std::make_integer_sequence<int, 9>{}, [&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                const int slot_off = (step & 1) * B_BYTES;
+                DC_NOW(ta);
+                // first half: MFMAs on half 0 (read during the previous step), reads of half 1 in flight beside them
+                rd_half(tap, 1, slot_off);
+                mfma_half(0);
+                // MFMAs lead each group: the wait in front of the first one then covers only reads issued a half-step ago
+#pragma unroll
+                for (int i = 0; i < NRD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD * (NMF / NRD), 0);
+                // mid-step hand-over: this wave's pieces of stage step+1 have landed (the halo prefetch issued after them in
+                // tap 0 may still be in flight at tap 1), its reads of stage `step` have returned; after the barrier
+                // everyone's have: stage step+1 visible, slot of stage `step` free for stage step+2
+                DC_NOW(tb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NHU) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                DC_NOW(tc);
+#ifdef DC_STAMP
+                s_work += tb - ta;
+                s_sync += tc - tb;
+#endif
+                // second half: MFMAs on half 1; reads of the next step's half 0, the DMA of stage step+2 (and in tap 0 the
+                // global loads of the next channel slice's halo, always issued so that the counted wait of tap 1 holds)
+                if (tap < 8) rd_half(tap + 1, 0, B_BYTES - slot_off);
+                issue_b_at(cc + (tap + 2) / 9, (tap + 2) % 9, step & 1);
+                if (tap == 0) issue_halo(more_c ? cc + 1 : cc);
+                mfma_half(1);
+                {
+                    constexpr int nrd2 = tap < 8 ? NRD : 0, nvm = tap == 0 ? NB + NHU : NB;
+                    constexpr int per = (NMF - nrd2) / nvm > 0 ? (NMF - nrd2) / nvm : 1;
+#pragma unroll
+                    for (int i = 0; i < nrd2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < nvm; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                    constexpr int rest = NMF - nrd2 - nvm * per;
+                    if constexpr (rest > 0) __builtin_amdgcn_sched_group_barrier(0x008, rest, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // (a group left open would take the next half-step's MFMAs)
+#ifdef DC_STAMP
+                DC_NOW(ta);
+                s_work += ta - tc;
+#endif
+                ++step;
+            });
+            if (more_c) {
+                // every wave passed the mid-step barrier of tap 8 with its halo reads returned: the image is free
+                DC_NOW(ta);
+                store_halo(cc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                rd_half(0, 0, (step & 1) * B_BYTES);
+#ifdef DC_STAMP
+                DC_NOW(tb);
+                s_halo += tb - ta;
+#endif
+            }
+        }
+    } else {
     // ---- main loop: per 64-channel slice, halo once, 9 taps; weight tiles ride the DMA ring
     issue_halo(c_begin);
 #pragma unroll
@@ -258,27 +417,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     store_halo(c_begin);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int step = 0;
+    DC_NOW(ts1);
     for (int cc = c_begin; cc < c_end; ++cc) {
         const bool more_c = cc + 1 < c_end;
         for (int tap = 0; tap < 9; ++tap, ++step) {
+            DC_NOW(ta);
             dc_ring_sync<DC_EXP_NO_DMA ? 0 : NB * (NSTB - 2)>(); // this wave's pieces of weight stage `step` have landed and its reads of
                                                                  // step-1 have returned; after the barrier everyone's have: halo image
                                                                  // visible, slot step-1 free
+            DC_NOW(tb);
             load_frags(tap, step % NSTB);
             if (tap == 0 && more_c) issue_halo(cc + 1);          // lands under the next eight K-steps
             issue_b(step + NSTB - 1, (step + NSTB - 1) % NSTB);
             mfma_frags();
+#ifdef DC_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            DC_NOW(tc);
+            s_sync += tb - ta;
+            s_work += tc - tb;
+#endif
         }
         if (more_c) {
+            DC_NOW(ta);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the halo image have returned
             __builtin_amdgcn_s_barrier();                        // every wave is past its last read of the halo image
             asm volatile("" ::: "memory");
             store_halo(cc + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible after the next K-step's barrier
+#ifdef DC_STAMP
+            DC_NOW(tb);
+            s_halo += tb - ta;
+#endif
         }
     }
+    }
     wait_vmcnt<0>();
+    DC_NOW(ts2);
 
     const long long slab = (long long)d.N * d.Ho * d.Wo * d.Cout;   // elements per split-K slab
     // ---- epilogue: lane holds out[pixel (ty, fr)][n = .. + 4*fq + 0..3].  Bias / time-embedding row / residual are all
@@ -310,6 +485,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 rr[tm][tn] = nb < d.Cout ? *(const bf16x4*)((const bf16_t*)d.residual + mrow[tm] * d.Cout + nb)
                                          : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
             }
+    }
+    // FAST tiles (16 consecutive pixels per tile row) leave through LDS: the finished bf16 tile is staged as [pixel][BN] rows and
+    // written out in 16-byte pieces, 20 lanes per 320-byte pixel row, instead of 8-byte pieces scattered over 16 rows per
+    // store instruction (the epilogue was store-issue-bound: 15k cycles per workgroup against 1.2k per K-step).
+    constexpr int SP = BN * 2 + 16;                              // staged row pitch (bytes)
+    const bool stg = FAST && !GENERIC && (d.Cout & 7) == 0;        // (the generic epilogue keeps its direct stores)
+    if (stg) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every wave is past its last fragment read: LDS is free
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     const bool want_gn = d.gn_part_out != nullptr && !e_split;
     f32x4 gs[TN], gq[TN];                                       // GroupNorm partials of this wave's output (gn_part_out)
@@ -347,12 +533,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                *(bf16x4*)((bf16_t*)d.out + off) = pk;
+                if (stg) *(bf16x4*)(smem + ((wm * TM + tm) * 16 + fr) * SP + ((wn * TN + tn) * 16 + 4 * fq) * 2) = pk;
+                else *(bf16x4*)((bf16_t*)d.out + off) = pk;
             }
         }
         // one pixel row group at a time: without the fence the straight-line epilogue is scheduled as one block and every
         // tile's operands are live at once (1,700 spilled registers in the specialised kernels)
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (stg) {
+        constexpr int CPR = BN / 8, NCH = TH * 16 * CPR / 256;   // 16-byte pieces per row / per thread
+        static_assert(TH * 16 * CPR % 256 == 0, "whole pieces per thread");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16_t* const obase = (bf16_t*)d.out + (((long long)n_img0 * d.Ho + oy0) * d.Wo + ox0) * d.Cout + n0;
+        u32x4 pv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, col = id - row * CPR;
+            pv[i] = *(const u32x4*)(smem + row * SP + col * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int id = tid + 256 * i, row = id / CPR, col = id - row * CPR;
+            if (n0 + col * 8 < d.Cout)
+                *(u32x4*)(obase + ((long long)(row >> 4) * d.Wo + (row & 15)) * d.Cout + col * 8) = pv[i];
+        }
     }
     if (want_gn) {
         // chunk = (pixel tile within the sample, wave row); dual tiles: one wave row = one whole 8x8 image
@@ -364,22 +572,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                                 fr == 0 && nb < d.Cout);
         }
     }
+#ifdef DC_STAMP
+    DC_NOW(ts3);
+    if (lane == 0 && d.splitk_ws && d.splitk <= 1) {
+        unsigned long long* o = (unsigned long long*)d.splitk_ws + ((long long)blockIdx.x * 4 + wave) * 8;
+        o[0] = ts0, o[1] = ts1, o[2] = ts2, o[3] = ts3, o[4] = s_sync, o[5] = s_work, o[6] = s_halo;
+    }
+#endif
 }
 
-template <int TM, int TN, int NSTB>
+template <int TM, int TN, int NSTB, bool FAST = false>
 int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
     const int sh = d.Wo < 16 ? 1 : 0;
     const bool dual = sh && TM == 4;
     const int nblk = (dual ? d.N / 2 : d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh))) * dc_cdiv(d.Cout, BN);
-    constexpr int HALO_ROWS = TM == 4 ? 200 : (TH + 2) * 18;
+    constexpr int HALO_ROWS = (TM == 4 && !FAST) ? 200 : (TH + 2) * 18;
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
-    const size_t lds = HALO_ROWS * 128 + NSTB * BN * 128;
+#ifdef DC_EXP_ONE_WG            // developer experiment: pad the allocation so one workgroup owns the CU
+    const size_t lds = 96 * 1024;
+#else
+    const size_t lds = HALO_ROWS * (FAST ? 160 : 128) + NSTB * BN * 128;
+#endif
     const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
 #define DC_TILE_LAUNCH1(GN, EPI)                                                                                \
     do {                                                                                                        \
-        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI>;                                                     \
+        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST>;                                                    \
         static std::atomic<unsigned long long> attr_done{0};                                                    \
         dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
@@ -448,6 +667,10 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
 {
     const bool n160 = use_n160(d);
     const int v = tile_variant(d);
+    if (DC_CONV_FAST && !d.upsample && d.Wo >= 16) {            // plain maps: half-step pipeline (see the kernel comment)
+        if (v == 4) return n160 ? launch_tile<4, 5, 2, true>(d, st) : launch_tile<4, 4, 2, true>(d, st);
+        return n160 ? launch_tile<2, 5, 2, true>(d, st) : launch_tile<2, 4, 2, true>(d, st);
+    }
     if (v == 4 || v == 8) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }
