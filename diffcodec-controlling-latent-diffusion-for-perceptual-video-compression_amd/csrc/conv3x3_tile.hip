@@ -240,11 +240,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
             __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + off), (lptr_t)(base + (wave + 4 * i) * 1024), 16, 0, 0);
     };
 
+    // FAST specialised epilogues: the bias (+ the sample's time-embedding row) is the accumulators' initial value — fetched in
+    // the prologue beside the halo, consumed at once (no registers live across the K loop), and the epilogue has no operand
+    // fetch left in front of its arithmetic (stamps: 7k of the epilogue's 10k cycles were those dependent L2 round trips)
+    constexpr bool BIAS_INIT = FAST && !GENERIC;
     f32x4 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BIAS_INIT) {
+            const int nb = n0 + (wn * TN + i) * 16 + 4 * fq;
+            if (nb < d.Cout) {
+                if (d.bias) v0 = *(const f32x4*)(d.bias + nb);
+                if (d.row_add) v0 += *(const f32x4*)(d.row_add + (long long)n_img * d.row_add_stride + nb);
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = v0;
+    }
 
     // One K-step (tap): all 2 x (TN + TM) fragment reads first (two register sets), then the step's LDS-DMA pieces, which
     // the schedule spreads between the MFMAs — same reasoning as gemm_dma.hip's K-step.
@@ -356,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 // everyone's have: stage step+1 visible, slot of stage `step` free for stage step+2
                 DC_NOW(tb);
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NHU) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (tap == 1) __builtin_amdgcn_s_waitcnt(0x0070 | NHU);          // vmcnt(NHU) lgkmcnt(0): a builtin, so that hipcc's
+                else __builtin_amdgcn_s_waitcnt(0x0070);                         // own wait-count bookkeeping sees the drain
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 DC_NOW(tc);
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     for (int tn = 0; tn < TN; ++tn) {
         const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!e_split && nb < d.Cout) {
+        if (!BIAS_INIT && !e_split && nb < d.Cout) {
             if (d.bias) v = *(const f32x4*)(d.bias + nb);
             if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)n_img * d.row_add_stride + nb);
         }
@@ -490,13 +503,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     // written out in 16-byte pieces, 20 lanes per 320-byte pixel row, instead of 8-byte pieces scattered over 16 rows per
     // store instruction (the epilogue was store-issue-bound: 15k cycles per workgroup against 1.2k per K-step).
     constexpr int SP = BN * 2 + 16;                              // staged row pitch (bytes)
-    const bool stg = FAST && !GENERIC && (d.Cout & 7) == 0;        // (the generic epilogue keeps its direct stores)
-    if (stg) {
+    constexpr bool stg = FAST && !GENERIC;                       // (the generic epilogue keeps its direct stores; the launcher
+                                                                 //  sends Cout % 8 != 0 to the other kernel)
+    if constexpr (stg) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every wave is past its last fragment read: LDS is free
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+#ifdef DC_STAMP
+    unsigned long long te1 = 0, te2 = 0, te3 = 0;
+    DC_NOW(te1);
+#endif
     const bool want_gn = d.gn_part_out != nullptr && !e_split;
     f32x4 gs[TN], gq[TN];                                       // GroupNorm partials of this wave's output (gn_part_out)
 #pragma unroll
@@ -506,14 +524,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int nb = n0 + (wn * TN + tn) * 16 + 4 * fq;
-            if (nb >= d.Cout) continue;
+            if (!stg && nb >= d.Cout) continue;                   // (staged: columns past Cout are dropped by the row pass)
             f32x4 v = acc[tn][tm];
             const long long off = mrow[tm] * d.Cout + nb;
             if (e_split) {                                        // this split's own fp32 slab: plain stores, no atomics
                 *(f32x4*)(d.splitk_ws + (long long)blockIdx.y * slab + off) = v;
                 continue;
             }
-            v += bv[tn];
+            if constexpr (!BIAS_INIT) v += bv[tn];
             if (e_act) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], e_act);
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                if (stg) *(bf16x4*)(smem + ((wm * TM + tm) * 16 + fr) * SP + ((wn * TN + tn) * 16 + 4 * fq) * 2) = pk;
+                if constexpr (stg) *(bf16x4*)(smem + ((wm * TM + tm) * 16 + fr) * SP + ((wn * TN + tn) * 16 + 4 * fq) * 2) = pk;
                 else *(bf16x4*)((bf16_t*)d.out + off) = pk;
             }
         }
@@ -541,26 +559,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         // tile's operands are live at once (1,700 spilled registers in the specialised kernels)
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (stg) {
+    if constexpr (stg) {
         constexpr int CPR = BN / 8, NCH = TH * 16 * CPR / 256;   // 16-byte pieces per row / per thread
         static_assert(TH * 16 * CPR % 256 == 0, "whole pieces per thread");
         __builtin_amdgcn_sched_barrier(0);
+        DC_NOW(te2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        bf16_t* const obase = (bf16_t*)d.out + (((long long)n_img0 * d.Ho + oy0) * d.Wo + ox0) * d.Cout + n0;
+        DC_NOW(te3);
+        bf16_t* const obase = (bf16_t*)d.out + (((long long)n_img0 * d.Ho + oy0) * d.Wo + ox0) * d.Cout + n0;   // block-uniform
         u32x4 pv[NCH];
+        int voff[NCH];                                           // element offset inside the tile's rows (small: 32-bit)
+        int row = tid / CPR, col = tid - row * CPR;              // piece tid + 256 i, advanced incrementally
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int id = tid + 256 * i, row = id / CPR, col = id - row * CPR;
             pv[i] = *(const u32x4*)(smem + row * SP + col * 16);
+            voff[i] = n0 + col * 8 < d.Cout ? ((row >> 4) * d.Wo + (row & 15)) * d.Cout + col * 8 : -1;
+            col += 256 % CPR;
+            row += 256 / CPR;
+            if (col >= CPR) {
+                col -= CPR;
+                ++row;
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int id = tid + 256 * i, row = id / CPR, col = id - row * CPR;
-            if (n0 + col * 8 < d.Cout)
-                *(u32x4*)(obase + ((long long)(row >> 4) * d.Wo + (row & 15)) * d.Cout + col * 8) = pv[i];
-        }
+        for (int i = 0; i < NCH; ++i)
+            if (voff[i] >= 0) *(u32x4*)(obase + voff[i]) = pv[i];
     }
     if (want_gn) {
         // chunk = (pixel tile within the sample, wave row); dual tiles: one wave row = one whole 8x8 image
@@ -577,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     if (lane == 0 && d.splitk_ws && d.splitk <= 1) {
         unsigned long long* o = (unsigned long long*)d.splitk_ws + ((long long)blockIdx.x * 4 + wave) * 8;
         o[0] = ts0, o[1] = ts1, o[2] = ts2, o[3] = ts3, o[4] = s_sync, o[5] = s_work, o[6] = s_halo;
+        o[7] = ((te1 - ts2) & 0xffff) | (((te2 - te1) & 0xffff) << 16) | (((te3 - te2) & 0xffff) << 32) | (((ts3 - te3) & 0xffff) << 48);
     }
 #endif
 }
@@ -667,7 +693,7 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
 {
     const bool n160 = use_n160(d);
     const int v = tile_variant(d);
-    if (DC_CONV_FAST && !d.upsample && d.Wo >= 16) {            // plain maps: half-step pipeline (see the kernel comment)
+    if (DC_CONV_FAST && !d.upsample && d.Wo >= 16 && (d.Cout & 7) == 0) {            // plain maps: half-step pipeline (see the kernel comment)
         if (v == 4) return n160 ? launch_tile<4, 5, 2, true>(d, st) : launch_tile<4, 4, 2, true>(d, st);
         return n160 ? launch_tile<2, 5, 2, true>(d, st) : launch_tile<2, 4, 2, true>(d, st);
     }

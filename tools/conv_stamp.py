@@ -43,6 +43,9 @@ print("median cycles per wave: prologue %.0f | K loop %.0f | epilogue %.0f | tot
 print("  K loop per step: sync (vmcnt+lgkmcnt wait + barrier) %.0f | fragment reads + DMA issue + MFMA issue %.0f | halo swap (per 9 steps) %.0f" %
       (med(t[:, 4]) / steps, med(t[:, 5]) / steps, med(t[:, 6]) / max(1, c // 64 - 1)))
 print("  MFMA cycles per step per wave (40 x 16): 640")
+e = ws.view(nblk * 4, 8).cpu()[:, 7]
+parts = [((e >> sh) & 0xffff).double().median().item() for sh in (0, 16, 32, 48)]
+print("  epilogue parts: operand loads + barrier-in %.0f | math + ds_write %.0f | barrier-mid %.0f | row reads + stores %.0f" % tuple(parts))
 ok = t[:, 0] > 0
 span = (t[ok, 3].max() - t[ok, 0].min()).item()
 print("kernel span %.0f cycles in %.1f us (event-timed) = %.2f GHz shader clock; waves stamped %d of %d" % (span, us, span / us / 1e3, int(ok.sum()), nblk * 4))
