@@ -88,16 +88,32 @@ def cpu_baseline(sds, threads, device_decode=None):
     return out
 
 
-def latest_pmc():
-    """HBM traffic of the dominant conv shape from committed rocprofv3 --pmc passes (counters cannot be read in-process)."""
-    for name in ("r02_pmc_igemm.json", "r01_pmc_igemm.json"):
+# PMC reference shape per kernel family (tools/pmc_conv.py launches exactly these; algorithmic bytes = inputs + weights + output)
+PMC_SHAPES = {"gemm_dma_kernel": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320)", 167976960),
+              "conv3x3_tile_kernel": ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360),
+              "attn_kernel": ("attention B=32 H=8 N=4096 d=40", 335544320)}
+
+
+def latest_pmc(family):
+    """HBM traffic per launch of the family's PMC reference shape, from the committed rocprofv3 --pmc passes (hardware counters
+    cannot be read in-process): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the gfx950 note of the guide."""
+    key = next((k for k in PMC_SHAPES if k in family), None)
+    for name in ("r02_pmc_summary.json",):
         p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            with open(p) as fh:
-                sh = json.load(fh)["shapes"][0]
-            return sh["hbm_bytes"], (f"HBM bytes per launch of {sh['shape']}: 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes "
-                                     f"(profiles/{name}), {sh['ratio']}x its algorithmic {sh['algorithmic_bytes']} B")
-    return None, "no PMC summary committed"
+        if key is None or not os.path.exists(p):
+            continue
+        with open(p) as fh:
+            summ = json.load(fh)
+        rows = [v for k, v in summ.items() if key in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        if not rows:
+            continue
+        r = rows[0]                                  # first launch group of the family = the reference shape
+        hbm = int((2 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024)
+        shape, alg = PMC_SHAPES[key]
+        return hbm, (f"HBM bytes per launch of {shape}: (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes "
+                     f"(profiles/{name}) = {hbm / alg:.3f}x its algorithmic {alg} B; `achieved` is the family aggregate over all of "
+                     f"its shapes in one step")
+    return None, "no PMC summary committed for this kernel family"
 
 
 def main():
@@ -284,7 +300,7 @@ def main():
                                  f"{by / (ms * 1e-3) / 1e9 if ms else 0:8.1f} GB/s  {shape}\n")
         dom = max((f for f in families if f["tflops"] > 50), key=lambda f: f["ms_per_step"])
         d = summ[dom["kernel"]]
-        traffic, traffic_note = latest_pmc()
+        traffic, traffic_note = latest_pmc(dom["kernel"])
         roof = dict(bound="mfma", achieved=dom["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=dom["frac_mfma_peak"],
                     traffic=traffic, traffic_note=traffic_note, kernel=dom["kernel"], launches_per_step=d["calls"],
                     avg_launch_us=round(d["ms"] * 1e3 / d["calls"], 2), kernel_ms_per_step=round(d["ms"], 2),

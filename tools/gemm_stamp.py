@@ -7,7 +7,7 @@ import torch
 from diffcodec_amd import lib, ops
 PKG = os.path.dirname(lib.LIB_PATH)
 so = "/tmp/libdc_stamp.so"
-srcs = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip"]
+srcs = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip"]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DDC_STAMP", "-o", so] +
                       [os.path.join(PKG, "csrc", s) for s in srcs])
 L = ctypes.CDLL(so)
@@ -23,7 +23,7 @@ nblk = math.ceil(m / 128) * math.ceil(cout / 160)
 ws = torch.zeros(nblk * 8, device="cuda", dtype=torch.int64)
 d = lib.ConvDesc(x1=x.data_ptr(), x2=0, w=pc.w.data_ptr(), bias=pc.bias.data_ptr(), gn_ab=0, row_add=0, residual=0, out=out.data_ptr(),
                  splitk_ws=ws.data_ptr(), N=n, H=h, W=h, C1=c, C2=0, Cout=cout, ksize=1, stride=1, pad=1, upsample=0, Ho=h, Wo=h,
-                 gn_silu=0, epilogue=0, out_f32=0, out_scale=1.0, splitk=1, gn_batch=0, act=0, row_add_stride=0, ln_stats=0, ln_colsum=0, stats_out=0)
+                 gn_silu=0, epilogue=0, out_f32=0, out_scale=1.0, splitk=1, gn_batch=0, act=0, row_add_stride=0, ln_stats=0, ln_colsum=0, stats_out=0, gn_part_out=0)
 for _ in range(3):
     assert L.dc_conv_igemm_bf16(ctypes.byref(d), torch.cuda.current_stream().cuda_stream) == 0
 torch.cuda.synchronize()
