@@ -14,6 +14,16 @@
 #include "../../include/diffcodec_hip.h"
 #include <cstdlib>
 
+// Developer-only phase stamps (tools/attn_stamp.py builds this file with -DDC_STAMP into a scratch .so): per-wave s_memtime sums of
+// the QK^T + row-max phase, the exp + PV phase and the staging + barrier phase of the long-context loop.
+#ifdef DC_STAMP
+__device__ unsigned long long dc_attn_stamp_buf[1 << 18];
+extern "C" int dc_attn_stamp_read(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dc_attn_stamp_buf), (size_t)n * 8); }
+#define DC_NOW(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#else
+#define DC_NOW(t) (void)0
+#endif
+
 namespace {
 
 constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key MFMA tiles)
@@ -184,6 +194,8 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     __syncthreads();
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, s_qk = 0, s_sm = 0, s_pv = 0, s_st = 0, st_0 = 0;
+    DC_NOW(st_0);
     auto process_tile = [&](int t, bool first) {
         const int buf = t & 1;
         const char* sK = smem + buf * BUF;
@@ -207,6 +219,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 for (int u = 0; u < QB; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][j], 0, 0, 0);
             }
 
+#ifdef DC_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        DC_NOW(st_b);
+#endif
         // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
         //      are one (packed) FMA feeding v_exp_f32 directly; key masking only exists in the ragged last tile.
         bf16x8 pf[QB][2][2];
@@ -292,6 +308,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
         // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
         // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
         // and receives d = block + j16 for the block's 4 keys; each V fragment feeds QB MFMAs.
+#ifdef DC_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        DC_NOW(st_c);
+#endif
         const char* vbase = sV + (4 * lh + ((lane & 15) >> 2)) * V_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int tt = 0; tt < NDT; ++tt) {
@@ -371,12 +391,28 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     if constexpr (!SHORT) {
         for (int t = 0; t < ntiles; ++t) {
             const bool more = t + 1 < ntiles;
+            DC_NOW(st_a);
             if (more) issue_loads(t + 1);
             process_tile(t, t == 0);
+#ifdef DC_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            DC_NOW(st_d);
+#endif
             if (more) store_lds((t & 1) ^ 1);
             __syncthreads();
+#ifdef DC_STAMP
+            DC_NOW(st_e);
+            s_qk += st_b - st_a, s_sm += st_c - st_b, s_pv += st_d - st_c, s_st += st_e - st_d;
+#endif
         }
         store_out();
+#ifdef DC_STAMP
+        DC_NOW(st_e);
+        if (lane == 0) {
+            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 4 + wave) * 8;
+            if ((long long)blockIdx.x * 4 + wave < (1 << 15)) o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0;
+        }
+#endif
     } else {
         if (ntiles > 1) {                                      // second key tile: staged once, like the first
             issue_loads(1);
