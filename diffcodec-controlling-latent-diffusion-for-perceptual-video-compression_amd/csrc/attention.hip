@@ -39,6 +39,9 @@ constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key M
 // subtract-and-rescale pass is the exception, not the rule.  The d = 40 kernel is VALU-issue-bound (64 exps + 32 converts +
 // 16 max3 per 28 MFMAs and tile): the 32 packed FMAs this removes were ~13 % of its VALU time.
 constexpr float RESCALE_THR = 4.0f;
+#ifndef DC_ATTN_EARLY_STAGE
+#define DC_ATTN_EARLY_STAGE 1                // developer A/B switch: 0 = the next tile is written to LDS after the PV MFMAs
+#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // V stays row-major [key][d] in LDS (one ds_write_b128 per staged vector); the PV MFMA's A operand (V^T: 4 consecutive
@@ -67,9 +70,17 @@ struct AttnArgs {
 // hipcc speculates its ~90 index/compare/select VALU instructions into every tile although they matter in the last one
 // only; the d = 40 kernel is VALU-issue-bound, so that was a quarter of its time).
 constexpr int SHORT_PASSES = 4;
-template <int D, int QB, bool SHORT, bool RAGGED>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
+// PP (ping-pong, long context only): ONE 8-wave workgroup per CU, two waves per SIMD FROM THE SAME workgroup, run half a tile
+// apart by construction.  Stamps (tools/attn_stamp.py) showed why the 4-wave form stops at ~50 % MFMA occupancy: its two
+// co-resident waves (two workgroups running identical code from the same start) stay IN PHASE, so their MFMA blocks contend for
+// the matrix pipe and then their exp/convert blocks contend for the VALU — per tile and SIMD the time was MFMA + VALU, not
+// max(MFMA, VALU).  Here a tile is two barrier-separated slots: waves 0-3 run {PV(t-1), QK^T(t)} while waves 4-7 run
+// softmax(t-1), then the roles swap.  Waves 0-3 stage K, waves 4-7 stage V; every wave executes the same number of barriers.
+template <int D, int QB, bool SHORT, bool RAGGED, bool PP = false>
+__global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel(const AttnArgs a)
 {
+    static_assert(!PP || !SHORT, "ping-pong is the long-context form");
+    constexpr int NWAVE = PP ? 8 : 4, NT = NWAVE * 64;
     constexpr int ND16 = (D + 15) / 16;              // K-steps of QK^T
     constexpr int NDT = (D + 31) / 32;               // 32-row output tiles of O^T
     constexpr int NV = D / 8;                        // 16-byte vectors per K/V row
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;
-    constexpr int QWG = 4 * QW * (SHORT ? SHORT_PASSES : 1);   // queries per workgroup
+    constexpr int QWG = NWAVE * QW * (SHORT ? SHORT_PASSES : 1);   // queries per workgroup
     const int qblocks = (a.Nq + QWG - 1) / QWG;
     const int bh = blockIdx.x / qblocks;
     const int qb = blockIdx.x - bh * qblocks;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     const bf16_t* __restrict__ V = a.v + (long long)b * a.Nk * a.vs + h * D;
 
     // zero both LDS buffers once: pad columns (d >= D) and never-written bytes must be finite zeros
-    for (int i = tid * 16; i < 2 * BUF; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < 2 * BUF; i += NT * 16) *(u32x4*)(smem + i) = u32x4{0u, 0u, 0u, 0u};
     if (ONES) {
         __syncthreads();
         if (tid < 2 * KV_TILE) {
@@ -186,24 +197,25 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     };
 
     __syncthreads();                  // zero-fill (and the ones column) complete before the first tile lands
-    issue_loads(0);
-    store_lds(0);
+    if constexpr (!PP) {
+        issue_loads(0);
+        store_lds(0);
+    }
     // every prologue load (the Q fragments too) has landed before the loop: otherwise hipcc's wait for Q sits INSIDE the loop
     // as vmcnt(0) in front of the first QK^T MFMA and drains the next tile's prefetch on every iteration
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0) only
-    __syncthreads();
+    if constexpr (!PP) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
+        __syncthreads();
+    }
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, s_qk = 0, s_sm = 0, s_pv = 0, s_st = 0, st_0 = 0;
     DC_NOW(st_0);
-    auto process_tile = [&](int t, bool first) {
-        const int buf = t & 1;
+    f32x16 s[QB][2];                   // S^T of the current key tile (QK^T -> softmax)
+    bf16x8 pf[QB][2][2];               // its probabilities as the PV MFMA's B operand (softmax -> PV)
+    // ---- S^T tiles (2 x 32 keys) for every query block: each K fragment feeds QB MFMAs.  K(t) lives in LDS buffer `buf`.
+    auto qk_part = [&](int buf) {
         const char* sK = smem + buf * BUF;
-        const char* sV = sK + K_BYTES;
-        const int kb = t * KV_TILE;
-
-        // ---- S^T tiles (2 x 32 keys) for every query block: each K fragment feeds QB MFMAs
-        f32x16 s[QB][2];
 #pragma unroll
         for (int u = 0; u < QB; ++u)
 #pragma unroll
@@ -219,13 +231,14 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 for (int u = 0; u < QB; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][j], 0, 0, 0);
             }
 
-#ifdef DC_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        DC_NOW(st_b);
-#endif
-        // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
-        //      are one (packed) FMA feeding v_exp_f32 directly; key masking only exists in the ragged last tile.
-        bf16x8 pf[QB][2][2];
+    };
+    // ---- online softmax.  The running max is kept on the RAW scores (scale > 0), the scale and the max subtraction
+    //      are one (packed) FMA feeding v_exp_f32 directly; key masking only exists in the ragged last tile.
+    float mloc_s[QB];                  // this tile's row maxima (rowmax -> softmax)
+    // key masking of the ragged last tile and the tile's row maxima: its own part so that the ping-pong form can run it behind the
+    // QK^T MFMAs (it balances the two slots: 1.28k cycles of MFMA block against 1.53k of softmax block before the move)
+    auto rowmax_part = [&](int t) {
+        const int kb = t * KV_TILE;
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
             if (RAGGED && kb + KV_TILE > a.Nk) {
@@ -246,6 +259,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
                 mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
+            mloc_s[u] = mloc;
+        }
+    };
+    auto softmax_part = [&](int t, bool first) {
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const float mloc = mloc_s[u];
             if (QOFF) {
                 // s already holds t = log2-domain score - offset.  Move the offset only where this tile's maximum runs ahead of it
                 // by more than the threshold (or on the first tile of a block, to anchor it at a real maximum).
@@ -305,13 +325,12 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             if (!ONES) l_run[u] += lsum;
         }
 
-        // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
-        // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
-        // and receives d = block + j16 for the block's 4 keys; each V fragment feeds QB MFMAs.
-#ifdef DC_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        DC_NOW(st_c);
-#endif
+    };
+    // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
+    // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
+    // and receives d = block + j16 for the block's 4 keys; each V fragment feeds QB MFMAs.  The V tile lives in buffer `buf`.
+    auto pv_part = [&](int buf) {
+        const char* sV = smem + buf * BUF + K_BYTES;
         const char* vbase = sV + (4 * lh + ((lane & 15) >> 2)) * V_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int tt = 0; tt < NDT; ++tt) {
@@ -329,6 +348,23 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
                         oacc[u][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8*)&av, pf[u][j][s2], oacc[u][tt], 0, 0, 0);
                 }
         }
+    };
+    auto process_tile = [&](int t, bool first, bool stage_next) {
+        qk_part(t & 1);
+        rowmax_part(t);
+#ifdef DC_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        DC_NOW(st_b);
+#endif
+        softmax_part(t, first);
+#ifdef DC_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        DC_NOW(st_c);
+#endif
+        // the next tile's K/V (in registers since the top of this tile) go to the other LDS buffer HERE, so the writes drain under
+        // the PV MFMAs instead of in front of the barrier
+        if (DC_ATTN_EARLY_STAGE && stage_next) store_lds((t & 1) ^ 1);
+        pv_part(t & 1);
     };
 
     // ---- finish: O[q][d] = O^T[d][q] / l
@@ -388,17 +424,98 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
     };
 
-    if constexpr (!SHORT) {
-        for (int t = 0; t < ntiles; ++t) {
-            const bool more = t + 1 < ntiles;
+    if constexpr (PP) {
+        const int grp = wave >> 2, w4 = wave & 3;              // group 0 stages K, group 1 stages V; w4 + 4i -> 16-byte vector of a row
+        u32x4 rs[NLD];
+        auto pp_issue = [&](int t) {                           // this group's operand of key tile t -> registers
+            int key = t * KV_TILE + lane;
+            if (RAGGED) key = key < a.Nk ? key : a.Nk - 1;
+            const bf16_t* __restrict__ src = grp ? V + (long long)key * a.vs : K + (long long)key * a.ks;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int vec = w4 + 4 * i;
+                if (vec < NV) rs[i] = *(const u32x4*)(src + vec * 8);
+            }
+        };
+        auto pp_store = [&](int buf) {                         // ... -> its half of LDS buffer `buf`
+            char* base = smem + buf * BUF + (grp ? K_BYTES : 0);
+            const int pitch = grp ? V_PITCH : K_PITCH;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int vec = w4 + 4 * i;
+                if (vec < NV) *(u32x4*)(base + lane * pitch + vec * 16) = rs[i];
+            }
+        };
+        // LDS buffer p & 1 holds the PAIR p = {K(p), V(p-1)}: exactly what the MFMA block of tile p reads.  Global slots: group 0
+        // runs its MFMA block of tile t in slot 2t and its softmax in slot 2t+1; group 1 one slot later.  Pair t+1 is written in
+        // slot 2t+1 (K by group 0 at the end of its softmax, V(t) by group 1 at the end of its MFMA block) into the buffer whose
+        // last reader (group 1, MFMA block t-1) finished in slot 2t-1, and is read from slot 2t+2 on.
+        const int T = ntiles;
+        pp_issue(0);                                           // K(0) | V(0)
+        if (grp == 0) pp_store(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the Q fragments too (see the 4-wave form)
+        __syncthreads();                                       // pair 0 visible (its V half is never read)
+        if (grp == 1) __syncthreads();                         // group 1 runs one slot behind
+        // tile 0 (peeled: no PV yet, and the softmax anchors its offset)
+        if (grp == 0 && 1 < T) pp_issue(1);                    // K(1): written at the end of this tile's softmax
+        qk_part(0);
+        rowmax_part(0);
+        if (grp == 1) pp_store(1);                             // V(0), in registers since the prologue
+        __syncthreads();
+        if (grp == 1 && 1 < T) pp_issue(1);                    // V(1): written at the end of the next MFMA block
+        softmax_part(0, true);
+        if (grp == 0 && 1 < T) pp_store(1);                    // K(1)
+        __syncthreads();
+        for (int t = 1; t < T; ++t) {
+            // MFMA block of tile t
             DC_NOW(st_a);
-            if (more) issue_loads(t + 1);
-            process_tile(t, t == 0);
+            if (grp == 0 && t + 1 < T) pp_issue(t + 1);
+            pv_part(t & 1);                                    // V(t-1), probabilities of tile t-1
+            __builtin_amdgcn_sched_barrier(0);                 // PV before QK^T: the probabilities die before the new scores are born
+            qk_part(t & 1);
+            rowmax_part(t);
+            if (grp == 1) pp_store((t + 1) & 1);               // V(t)
+#ifdef DC_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            DC_NOW(st_b);
+#endif
+            __syncthreads();
+            // softmax block of tile t
+            DC_NOW(st_c);
+            if (grp == 1 && t + 1 < T) pp_issue(t + 1);
+            softmax_part(t, false);
+            if (grp == 0 && t + 1 < T) pp_store((t + 1) & 1);  // K(t+1)
 #ifdef DC_STAMP
             __builtin_amdgcn_sched_barrier(0);
             DC_NOW(st_d);
 #endif
-            if (more) store_lds((t & 1) ^ 1);
+            __syncthreads();
+#ifdef DC_STAMP
+            DC_NOW(st_e);
+            s_qk += st_b - st_a, s_sm += st_c - st_b, s_pv += st_d - st_c, s_st += st_e - st_d;   // MFMA block | barrier | softmax | barrier
+#endif
+        }
+        pv_part(T & 1);                                        // V(T-1)
+        if (grp == 0) __syncthreads();                         // group 0's last barrier; group 1 is already past its last one
+#ifdef DC_STAMP
+        DC_NOW(st_e);
+        if (lane == 0 && (long long)blockIdx.x * 8 + wave < (1 << 15)) {
+            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;
+            o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0, o[5] = 1;
+        }
+#endif
+        store_out();
+    } else if constexpr (!SHORT) {
+        for (int t = 0; t < ntiles; ++t) {
+            const bool more = t + 1 < ntiles;
+            DC_NOW(st_a);
+            if (more) issue_loads(t + 1);
+            process_tile(t, t == 0, more);
+#ifdef DC_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            DC_NOW(st_d);
+#endif
+            if (!DC_ATTN_EARLY_STAGE && more) store_lds((t & 1) ^ 1);
             __syncthreads();
 #ifdef DC_STAMP
             DC_NOW(st_e);
@@ -423,7 +540,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
             const bool has_next = pass + 1 < SHORT_PASSES && q0 + 4 * QW < a.Nq;
             bf16x8 qn[QB][ND16];
             if (has_next) fetch_q(q0 + 4 * QW, qn);            // next block's queries fly while this one computes
-            for (int t = 0; t < ntiles; ++t) process_tile(t, t == 0);
+            for (int t = 0; t < ntiles; ++t) process_tile(t, t == 0, false);
             store_out();
             if (!has_next) break;
             q0 += 4 * QW;
@@ -436,19 +553,19 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_kernel(const Attn
     }
 }
 
-template <int D, int QB, bool SHORT, bool RAGGED>
+template <int D, int QB, bool SHORT, bool RAGGED, bool PP = false>
 int launch_qb_r(const AttnArgs& a, hipStream_t st)
 {
     constexpr int ND16 = (D + 15) / 16, NDT = (D + 31) / 32;
     constexpr int KP16 = (ND16 * 2) | 1;
     constexpr int BUF = KV_TILE * KP16 * 16 + KV_TILE * v_pitch_bytes(NDT);
     const size_t lds = 2 * BUF + (SHORT ? 4 * (32 * QB) * (D * 2 + 16) : 0);
-    auto kern = attn_kernel<D, QB, SHORT, RAGGED>;
+    auto kern = attn_kernel<D, QB, SHORT, RAGGED, PP>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
-    constexpr int QWG = 128 * QB * (SHORT ? SHORT_PASSES : 1);
+    constexpr int QWG = (PP ? 256 : 128) * QB * (SHORT ? SHORT_PASSES : 1);
     const int qblocks = (a.Nq + QWG - 1) / QWG;
-    hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.B * a.heads * qblocks), dim3(PP ? 512 : 256), lds, st, a);
     return dc_launch_status();
 }
 
@@ -471,6 +588,13 @@ int launch(const AttnArgs& a, hipStream_t st)
         const long long wgs2 = (long long)a.B * a.heads * ((a.Nq + 255) / 256);
         if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) {
             if (short_ctx && wgs2 / SHORT_PASSES >= 512) return launch_qb<D, 2, true>(a, st);
+            // long context with at least one 8-wave workgroup per CU: the ping-pong form (DC_ATTN_PP=0/1: developer A/B knob)
+            static const int force_pp = getenv("DC_ATTN_PP") ? atoi(getenv("DC_ATTN_PP")) : -1;
+            const long long wgs_pp = (long long)a.B * a.heads * ((a.Nq + 511) / 512);
+            if (!short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
+                if ((a.Nk % KV_TILE) != 0) return launch_qb_r<D, 2, false, true, true>(a, st);
+                return launch_qb_r<D, 2, false, false, true>(a, st);
+            }
             return launch_qb<D, 2, false>(a, st);
         }
     }

@@ -436,6 +436,27 @@ def test_attention_forced_rescale_and_strided_views(ops):
     close(out.float().cpu(), ref, rtol=2e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("b,heads,nq,nk,d", [(32, 8, 4096, 4096, 40),   # the 64x64 self-attention of the decode loop at model batch 32
+                                             (40, 8, 1100, 1000, 40),   # ragged: Nq not a multiple of 512, Nk not of 64
+                                             (64, 8, 512, 256, 32), (36, 8, 600, 320, 16)])
+def test_attention_ping_pong_form(ops, b, heads, nq, nk, d):
+    """Long-context shapes that take the 8-wave ping-pong kernel (>= 256 workgroups of 512 queries, Nk >= 256): against SDPA on a
+    sample of the batch, and bit-identical from launch to launch."""
+    g = torch.Generator().manual_seed(21)
+    c = heads * d
+    q = bf(torch.randn(b, nq, c, generator=g))
+    k = bf(torch.randn(b, nk, c, generator=g))
+    v = bf(torch.randn(b, nk, c, generator=g))
+    k[1, nk - 3, :d] = bf(q[1, 5, :d] * 6.0)           # a late key spike: the offset of head 0 / sample 1 has to move
+    qd, kd, vd = (t.to(DEV, torch.bfloat16) for t in (q, k, v))
+    out = ops.attention(qd, kd, vd, heads)
+    assert torch.equal(out, ops.attention(qd, kd, vd, heads))
+    for bi in (0, 1, b - 1):
+        qh, kh, vh = (t[bi:bi + 1].view(1, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+        ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(1, nq, c)
+        close(out[bi:bi + 1].float().cpu(), ref, rtol=2e-2, atol=1e-2)
+
+
 def test_softmax_rows(ops):
     g = torch.Generator().manual_seed(13)
     s = torch.randn(37, 4096, generator=g) * 4

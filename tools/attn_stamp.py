@@ -33,4 +33,6 @@ m = lambda c: t[:, c].median().item()
 print("waves sampled", len(t), "key tiles per wave", tiles)
 print("median cycles per key tile and wave: QK^T + row max %.0f | exp + convert (+ rescale) %.0f | PV %.0f | stage next tile + barrier %.0f | sum %.0f" %
       (m(0) / tiles, m(1) / tiles, m(2) / tiles, m(3) / tiles, (m(0) + m(1) + m(2) + m(3)) / tiles))
+if t[:, 5].max() > 0:
+    print("  (ping-pong form: the four columns are MFMA block {PV(t-1), QK^T(t)} | barrier wait | softmax block | barrier wait)")
 print("MFMA floor per tile and wave: QK^T 12 x 32 = 384, PV 16 x 32 = 512;  whole wave %.0f cycles" % m(4))
