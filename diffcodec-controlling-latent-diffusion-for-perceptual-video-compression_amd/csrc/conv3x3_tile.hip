@@ -62,7 +62,8 @@ __device__ __forceinline__ void wait_vmcnt()
 // activation), 1 = bias (+ time-embedding row) -> bf16, 2 = the same + scaled residual add.  gn_part_out stays a run-time,
 // workgroup-uniform test outside the loops.
 //
-// FAST (plain maps at least 16 wide, no fused upsample; NSTB == 2): the halo image uses 160-byte pixel rows WITHOUT the XOR
+// FAST (plain maps at least 16 wide, no fused upsample; NSTB == 2, or 4 for grids of at most one workgroup per CU, whose K loop
+// is otherwise paced by one weight-DMA round trip per tap): the halo image uses 160-byte pixel rows WITHOUT the XOR
 // swizzle (16 consecutive pixels at one channel chunk are still bank-conflict-free), so a tap is an immediate offset from one
 // per-lane base address and the nine taps are unrolled with no address arithmetic left in the K loop; and the fragment reads
 // are software-pipelined ACROSS K-steps in two half-steps (32 channels each): while the MFMAs of one half run, the reads of
@@ -71,7 +72,7 @@ __device__ __forceinline__ void wait_vmcnt()
 template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
-    static_assert(!FAST || NSTB == 2, "the half-step pipeline is written for the two-slot weight ring");
+    static_assert(!FAST || NSTB == 2 || NSTB == 4, "the half-step pipeline indexes its weight ring with step & (NSTB - 1)");
     constexpr bool GENERIC = EPI == 0;
     const bool e_split = GENERIC && d.splitk > 1;
     const bool e_res = GENERIC ? (d.residual != nullptr && d.splitk <= 1) : EPI == 2;
@@ -345,14 +346,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         rd_half(0, 0, 0);
-        issue_b(1, 1);
+#pragma unroll
+        for (int st = 1; st < NSTB; ++st) issue_b(st, st);
         int step = 0;
         DC_NOW(ts1);
         for (int cc = c_begin; cc < c_end; ++cc) {
             const bool more_c = cc + 1 < c_end;
             dc_static_for(std::make_integer_sequence<int, 9>{}, [&](auto tap_c) {
                 constexpr int tap = decltype(tap_c)::value;
-                const int slot_off = (step & 1) * B_BYTES;
+                const int slot_off = (step & (NSTB - 1)) * B_BYTES;
                 DC_NOW(ta);
                 // first half: MFMAs on half 0 (read during the previous step), reads of half 1 in flight beside them
                 rd_half(tap, 1, slot_off);
@@ -369,8 +371,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 // everyone's have: stage step+1 visible, slot of stage `step` free for stage step+2
                 DC_NOW(tb);
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap == 1) __builtin_amdgcn_s_waitcnt(0x0070 | NHU);          // vmcnt(NHU) lgkmcnt(0): a builtin, so that hipcc's
-                else __builtin_amdgcn_s_waitcnt(0x0070);                         // own wait-count bookkeeping sees the drain
+                // vmcnt(N) lgkmcnt(0) as a builtin, so that hipcc's own wait-count bookkeeping sees the drain.  N = the pieces of the
+                // NSTB - 2 younger stages, plus the halo prefetch while it is younger than stage step+1 (taps 1 .. NSTB-1)
+                constexpr int VMN = NB * (NSTB - 2) + ((tap >= 1 && tap <= NSTB - 1) ? NHU : 0);
+                static_assert(VMN < 64, "vmcnt field");
+                __builtin_amdgcn_s_waitcnt(0x0070 | (VMN & 15) | ((VMN >> 4) << 14));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 DC_NOW(tc);
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #endif
                 // second half: MFMAs on half 1; reads of the next step's half 0, the DMA of stage step+2 (and in tap 0 the
                 // global loads of the next channel slice's halo, always issued so that the counted wait of tap 1 holds)
-                if (tap < 8) rd_half(tap + 1, 0, B_BYTES - slot_off);
-                issue_b_at(cc + (tap + 2) / 9, (tap + 2) % 9, step & 1);
+                if (tap < 8) rd_half(tap + 1, 0, ((step + 1) & (NSTB - 1)) * B_BYTES);
+                issue_b_at(cc + (tap + NSTB) / 9, (tap + NSTB) % 9, step & (NSTB - 1));
                 if (tap == 0) issue_halo(more_c ? cc + 1 : cc);
                 mfma_half(1);
                 {
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                rd_half(0, 0, (step & 1) * B_BYTES);
+                rd_half(0, 0, (step & (NSTB - 1)) * B_BYTES);
 #ifdef DC_STAMP
                 DC_NOW(tb);
                 s_halo += tb - ta;
@@ -694,6 +699,14 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     const bool n160 = use_n160(d);
     const int v = tile_variant(d);
     if (DC_CONV_FAST && !d.upsample && d.Wo >= 16 && (d.Cout & 7) == 0) {            // plain maps: half-step pipeline (see the kernel comment)
+        // at most one workgroup per CU (one- or two-frame decodes): a four-slot weight ring, three taps of weights in flight
+        static const int deep = getenv("DC_CONV_DEEP") ? atoi(getenv("DC_CONV_DEEP")) : 1;      // developer A/B knob
+        const int th = v == 4 ? 8 : 4, bn = n160 ? 160 : 128;
+        const long long wgs = (long long)d.N * (d.Ho / th) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
+        if (deep && wgs <= 256) {
+            if (v == 4) return n160 ? launch_tile<4, 5, 4, true>(d, st) : launch_tile<4, 4, 4, true>(d, st);
+            return n160 ? launch_tile<2, 5, 4, true>(d, st) : launch_tile<2, 4, 4, true>(d, st);
+        }
         if (v == 4) return n160 ? launch_tile<4, 5, 2, true>(d, st) : launch_tile<4, 4, 2, true>(d, st);
         return n160 ? launch_tile<2, 5, 2, true>(d, st) : launch_tile<2, 4, 2, true>(d, st);
     }

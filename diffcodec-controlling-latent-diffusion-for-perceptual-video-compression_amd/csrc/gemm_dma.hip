@@ -576,6 +576,14 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
     if (force_nst == 3 && big >= 256) return n160 ? launch_gemm<4, 5, 3>(d, st) : launch_gemm<4, 4, 3>(d, st);
     if (big >= 256) return n160 ? launch_gemm<4, 5, 2, false, true>(d, st) : launch_gemm<4, 4, 2, false, true>(d, st);
+    // Grids that cannot even put one workgroup on every CU (the 16x16 / 8x8 levels of a one- or two-frame decode) are bound by
+    // the serial K loop: one LDS-DMA round trip per 64-wide step.  They take a deeper ring — the whole CU's LDS for one
+    // workgroup, three or four stages in flight instead of one — with the same tile shape (so the statistics / GroupNorm partial
+    // layouts are unchanged).  M = 512, N = 1280, K = 1280: 26 -> see tools/bench_gemm.py 2.
+    static const int deep = getenv("DC_GEMM_DEEP") ? atoi(getenv("DC_GEMM_DEEP")) : 1;        // developer A/B knob
+    const long long small = ((M + 63) / 64) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
+    const int KT = (d.C1 + d.C2) >> 6;
+    if (deep && small <= 256 && KT >= 6) return n160 ? launch_gemm<2, 5, 4, false, true>(d, st) : launch_gemm<2, 4, 5, false, true>(d, st);
     return n160 ? launch_gemm<2, 5, 2, false, true>(d, st) : launch_gemm<2, 4, 3, false, true>(d, st);
 }
 

@@ -117,7 +117,9 @@ CONV_CASES = [
     (1, 16, 16, 64, 0, 64, 3, 2, 0, False),         # asymmetric pad (VAE encoder)
     (1, 8, 8, 64, 0, 128, 3, 1, 1, True),           # fused nearest-2x upsample
     (2, 8, 8, 320, 0, 320, 1, 1, 1, False),         # 1x1
-    (2, 64, 64, 320, 0, 320, 3, 1, 1, False),       # UNet 64x64 ResBlock conv (large tile path)
+    (2, 64, 64, 320, 0, 320, 3, 1, 1, False),       # UNet 64x64 ResBlock conv (large tile path; <= 256 workgroups: four-slot weight ring)
+    (10, 64, 64, 128, 64, 320, 3, 1, 1, False),     # the same path with > 256 workgroups: two-slot ring, two workgroups per CU, skip concat
+    (9, 32, 16, 192, 0, 256, 3, 1, 1, False),       # 128-column tiles, 4-row tiles, batch not a power of two
     (2, 8, 8, 1280, 1280, 1280, 3, 1, 1, False),    # UNet 8x8 up-block conv (split-K path)
 ]
 
