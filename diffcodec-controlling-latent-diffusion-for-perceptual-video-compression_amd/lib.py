@@ -28,7 +28,8 @@ class ConvDesc(ctypes.Structure):
 # name -> argtypes (every symbol include/diffcodec_hip.h declares; tests/test_abi.py cross-checks the header)
 SIGNATURES = {
     "dc_splat_soft_f32": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
-    "dc_splat_sum_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "dc_splat_sum_f32": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "dc_splat_ws_bytes": [i32, i32, i32],
     "dc_occlusion_mask_f32": [vp, vp, vp, vp, i32, i32, i32, vp],
     "dc_flow_resize_normalize_f32": [vp, i64, vp, i32, i32, i32, i32, i32, vp],
     "dc_flow_resize_divide_f32": [vp, i64, vp, i32, i32, i32, i32, i32, f32, f32, vp],
@@ -94,7 +95,7 @@ def load():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args
-        fn.restype = c_longlong if name == "dc_conv_igemm_ws_bytes" else c_int
+        fn.restype = c_longlong if name in ("dc_conv_igemm_ws_bytes", "dc_splat_ws_bytes") else c_int
     lib.dc_gn_stats_chunks.restype = c_int
     _lib = lib
     return lib

@@ -525,18 +525,24 @@ def vae_sample_latents(moments_nhwc_f32, noise, scale):
 
 
 # ------------------------------------------------------------------------------------------ splat stage (fp32 NCHW)
+def _splat_ws(n, h, w, device):
+    """Scratch of the deterministic splat (cell bins; dc_splat_ws_bytes)."""
+    return torch.empty((int(lib.load().dc_splat_ws_bytes(int(n), int(h), int(w))),), device=device, dtype=torch.uint8)
+
+
 def splat_soft(x, flow, metric, mask=None):
     for t, nm in ((x, "in"), (flow, "flow"), (metric, "metric")):
         _chk(t, F32, nm)
     n, c, h, w = x.shape
     assert flow.shape == (n, 2, h, w) and metric.shape == (n, 1, h, w)
     out = torch.empty_like(x)
-    ws = torch.empty((n, c + 1, h, w), device=x.device, dtype=F32)
-    # algorithmic traffic: reads (C+1+2) r^2, read-modify-write 4 (C+1) r^2 accumulator floats, + normalise pass
+    ws = _splat_ws(n, h, w, x.device)
+    # algorithmic traffic (SURVEY.md §8 a10, gather form): flow + metric + bins once per (target, channel) source visit (~1 source per
+    # corner list: 4 visits), in read once per visit, out written once
     lib.call("dc_splat_soft_f32", x.data_ptr(), flow.data_ptr(), metric.data_ptr(), _ptr(mask), out.data_ptr(), ws.data_ptr(),
              n, c, h, w, _stream(),
              meta=_meta("splat kernels (softsplat 'soft')", f"N={n} C={c} {h}x{w}", 10.0 * n * (c + 1) * h * w,
-                        4.0 * n * h * w * ((c + 3) + 4 * (c + 1) + 2 * (c + 1))))
+                        4.0 * n * h * w * (4 * c + c + 12)))
     return out
 
 
@@ -545,7 +551,8 @@ def splat_sum(x, flow):
     _chk(flow, F32, "flow")
     n, c, h, w = x.shape
     out = torch.empty_like(x)
-    lib.call("dc_splat_sum_f32", x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w, _stream())
+    ws = _splat_ws(n, h, w, x.device)
+    lib.call("dc_splat_sum_f32", x.data_ptr(), flow.data_ptr(), out.data_ptr(), ws.data_ptr(), n, c, h, w, _stream())
     return out
 
 
@@ -554,7 +561,7 @@ def occlusion_mask(flow_a, flow_b):
     _chk(flow_b, F32, "flow_b")
     n, _, h, w = flow_a.shape
     m = torch.empty((n, 1, h, w), device=flow_a.device, dtype=F32)
-    ws = torch.empty((n, 3, h, w), device=flow_a.device, dtype=F32)
+    ws = _splat_ws(n, h, w, flow_a.device)
     lib.call("dc_occlusion_mask_f32", flow_a.data_ptr(), flow_b.data_ptr(), m.data_ptr(), ws.data_ptr(), n, h, w, _stream())
     return m
 

@@ -28,14 +28,17 @@ extern "C" {
 /* ------------------------------------------------------------------ forward splatting (fp32, NCHW) */
 /* Replaces cuda_launch(cuda_kernel('softsplat_out', ...)) — controlnet/softsplat.py:284-345 — together
  * with the 'soft' wrapper math of softsplat.py:246-247,253-270 and the optional `warped*(1-mask)` of
- * control_utils.py:69-70.  acc_ws: fp32 [N,C+1,H,W] scratch.  metric [N,1,H,W]; mask [N,1,H,W] or NULL. */
+ * control_utils.py:69-70.  Deterministic gather form (sources binned by landing cell, every target sums its sources in
+ * ascending raster order): bit-identical from run to run.  ws: scratch of dc_splat_ws_bytes(N, H, W) bytes (any contents).
+ * metric [N,1,H,W]; mask [N,1,H,W] or NULL. */
+long long dc_splat_ws_bytes(int N, int H, int W);
 int dc_splat_soft_f32(const float* in, const float* flow, const float* metric, const float* mask,
-                      float* out, float* acc_ws, int N, int C, int H, int W, void* stream);
-/* 'sum' mode: out = splat(in, flow) (softsplat.py:235,251).  out is zeroed here. */
-int dc_splat_sum_f32(const float* in, const float* flow, float* out, int N, int C, int H, int W, void* stream);
+                      float* out, void* ws, int N, int C, int H, int W, void* stream);
+/* 'sum' mode: out = splat(in, flow) (softsplat.py:235,251); bit-exact with the sequential restatement oracle/splat_oracle.c. */
+int dc_splat_sum_f32(const float* in, const float* flow, float* out, void* ws, int N, int C, int H, int W, void* stream);
 /* compute_mask(a, b) — controlnet/control_utils.py:11-17: occ = (|| b + softsplat(a, b, ones, 'soft') ||_2 > 0.3).
- * acc_ws: fp32 [N,3,H,W]. */
-int dc_occlusion_mask_f32(const float* flow_a, const float* flow_b, float* mask_out, float* acc_ws,
+ * ws: dc_splat_ws_bytes(N, H, W) bytes. */
+int dc_occlusion_mask_f32(const float* flow_a, const float* flow_b, float* mask_out, void* ws,
                           int N, int H, int W, void* stream);
 /* resize_and_normalize_flow_batched — controlnet/control_utils.py:74-97 (bilinear, align_corners=False,
  * then u/((w-1)/2), v/((h-1)/2)).  src [N,2,H,W] with batch stride `src_batch_stride` floats (lets the

@@ -50,9 +50,32 @@ def test_splat_soft_matches_oracle(ops):
         mask = (torch.rand(n, 1, h, w, generator=g) > 0.5).float()
         ref = S.softsplat(x, flow, m, "soft") * (1 - mask)
         out = ops.splat_soft(x.to(DEV), flow.to(DEV), m.to(DEV), mask.to(DEV)).cpu()
-        close(out, ref, rtol=1e-4, atol=1e-5)      # fp32; only the atomic summation order differs
+        close(out, ref, rtol=1e-4, atol=1e-5)      # fp32; same summation order, device expf vs libm expf
+        assert torch.equal(out, ops.splat_soft(x.to(DEV), flow.to(DEV), m.to(DEV), mask.to(DEV)).cpu())   # run-to-run bit-identical
         ref_sum = S.splat_sum(x, flow)
-        close(ops.splat_sum(x.to(DEV), flow.to(DEV)).cpu(), ref_sum, rtol=1e-4, atol=1e-5)
+        # 'sum' mode has no transcendental: the gather adds every target's sources in ascending raster order with un-contracted
+        # fp32 operations, i.e. exactly the sequential oracle's arithmetic -> bit-exact
+        assert torch.equal(ops.splat_sum(x.to(DEV), flow.to(DEV)).cpu(), ref_sum)
+
+
+def test_splat_pathological_flows(ops):
+    """Every source landing in one cell (a k-way collision: the rank pass and the 4-way merge see long segments), everything
+    leaving the map, landing points exactly on the map border, and a non-square map: bit-exact against the sequential oracle."""
+    from oracle import splat as S
+    g = torch.Generator().manual_seed(7)
+    n, c, h, w = 2, 5, 24, 40
+    x = torch.randn(n, c, h, w, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    collapse = torch.stack([7.25 - xs, 3.5 - ys])[None].repeat(n, 1, 1, 1)                 # all 960 sources -> (7.25, 3.5)
+    away = torch.full((n, 2, h, w), 1.0e4)
+    away[1, :, 5, 6] = torch.tensor([float(w - 1 - 6), float(h - 1 - 5)])                # one source exactly onto the last pixel
+    edge = torch.stack([-1.0 - xs + (xs % 3) * 0.5, -0.5 - ys + (ys % 2)])[None].repeat(n, 1, 1, 1)   # columns -1 .. 0, rows -0.5 / 0.5
+    smooth = torch.randn(n, 2, h, w, generator=g) * 1.5
+    for flow in (collapse, away, edge, smooth):
+        out = ops.splat_sum(x.to(DEV), flow.to(DEV)).cpu()
+        assert torch.equal(out, S.splat_sum(x, flow))
+        m = torch.randn(n, 1, h, w, generator=g)
+        close(ops.splat_soft(x.to(DEV), flow.to(DEV), m.to(DEV)).cpu(), S.softsplat(x, flow, m, "soft"), rtol=1e-4, atol=1e-5)
 
 
 def test_occlusion_mask_and_flow_resize(ops):
