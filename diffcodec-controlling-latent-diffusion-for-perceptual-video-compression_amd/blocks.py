@@ -12,9 +12,11 @@ from . import ops
 from .ops import PackedConv
 
 
-# measured (profiles/r01_igemm_shapes_frames16.txt): the GN-on-load 1x1 igemm runs at ~250-350 TFLOP/s, the DMA GEMM at
-# 400-750; the extra elementwise pass only pays for itself below this many rows
-PROJ_IN_FUSE_MIN_ROWS = int(os.environ.get("DC_PROJ_IN_FUSE_MIN_ROWS", "65536"))
+# Transformer2DModel.norm + proj_in: GroupNorm is applied by its own HBM-bound pass and the 1x1 runs on the LDS-DMA GEMM, whose
+# epilogue also writes the LayerNorm row statistics norm1 needs.  The alternative (GroupNorm affine inside the gather GEMM's load
+# stage + a separate row-statistics pass) was the round-1 choice above 65,536 rows; measured again in round 2 on one box it costs
+# +5.5 ms per 16-frame step (igemm 26 -> 14 ms against +3.5 ms gn_apply and +5.8 ms GEMM).  DC_PROJ_IN_FUSE_MIN_ROWS re-enables it (A/B).
+PROJ_IN_FUSE_MIN_ROWS = int(os.environ.get("DC_PROJ_IN_FUSE_MIN_ROWS", str(1 << 62)))
 # LayerNorm folded into the following linear's weights + epilogue (ops.PackedConv(ln=...)): removes the three standalone
 # LayerNorm passes of every BasicTransformerBlock.  DC_LN_FOLD=0 keeps the separate dc_layernorm_bf16 launches (A/B).
 LN_FOLD = os.environ.get("DC_LN_FOLD", "1") != "0"

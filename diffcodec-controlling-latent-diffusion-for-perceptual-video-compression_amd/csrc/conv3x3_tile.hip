@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                if constexpr (stg) *(bf16x4*)(smem + ((wm * TM + tm) * 16 + fr) * SP + ((wn * TN + tn) * 16 + 4 * fq) * 2) = pk;
+                if constexpr (stg) *(bf16x4*)(smem + ((wm * TM + tm) * 16 + fr) * SP + ((((wn * TN + tn) * 16 + 4 * fq) * 2) ^ dc_stage_swz(fr))) = pk;
                 else *(bf16x4*)((bf16_t*)d.out + off) = pk;
             }
         }
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         int row = tid / CPR, col = tid - row * CPR;              // piece tid + 256 i, advanced incrementally
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            pv[i] = *(const u32x4*)(smem + row * SP + col * 16);
+            pv[i] = dc_stage_unswz(*(const u32x4*)(smem + row * SP + col * 16), row);
             voff[i] = n0 + col * 8 < d.Cout ? ((row >> 4) * d.Wo + (row & 15)) * d.Cout + col * 8 : -1;
             col += 256 % CPR;
             row += 256 / CPR;

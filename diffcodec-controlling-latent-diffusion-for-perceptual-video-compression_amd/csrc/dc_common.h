@@ -113,6 +113,17 @@ __device__ __forceinline__ void dc_gn_partial_store(f32x4 s, f32x4 q, float* __r
     }
 }
 
+// Staged bf16 output tiles ([row][columns] with a 16-byte-multiple pitch, written as 8-byte pieces by the MFMA layout: 16 lanes =
+// 16 consecutive rows at one column offset): whatever the pitch, rows r and r + 8 fall on the same banks (the pitch in dwords is a
+// multiple of 4, so only 8 of the 16 rows land on distinct bank pairs) — a 2-way conflict on every ds_write_b64.  Rows 8-15 of each
+// 16-row group therefore swap the two 8-byte halves of every 16-byte piece (XOR 8 on the byte offset), which moves them onto the
+// free bank pairs; the row pass swaps the halves back in registers.
+__device__ __forceinline__ int dc_stage_swz(int row) { return ((row >> 3) & 1) << 3; }
+__device__ __forceinline__ u32x4 dc_stage_unswz(u32x4 v, int row)
+{
+    return ((row >> 3) & 1) ? u32x4{v[2], v[3], v[0], v[1]} : v;
+}
+
 static inline int dc_launch_status()
 {
     hipError_t e = hipGetLastError();

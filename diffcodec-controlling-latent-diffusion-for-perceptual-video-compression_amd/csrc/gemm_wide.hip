@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
-                *(bf16x4*)(smem + row * PITCH + (((wn * TN + 2 * tp) * 16) / 2 + 4 * fq) * 2) = pk;
+                *(bf16x4*)(smem + row * PITCH + (((((wn * TN + 2 * tp) * 16) / 2 + 4 * fq) * 2) ^ dc_stage_swz(row))) = pk;
             }
         } else {
             float st1 = 0.f, st2 = 0.f;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                *(bf16x4*)(smem + row * PITCH + nl * 2) = pk;
+                *(bf16x4*)(smem + row * PITCH + ((nl * 2) ^ dc_stage_swz(row))) = pk;
                 if (EPI == 1 || EPI == 2) {
                     const float cm = nb < d.Cout ? 1.f : 0.f;
                     st1 += cm * ((v[0] + v[1]) + (v[2] + v[3]));
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
     for (int i = tid; i < BM * pieces; i += 512) {
         const int row = i / pieces, pc = i - row * pieces;
         const int m = m0 + row, c = col0 + pc * 8;
-        if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = *(const u32x4*)(smem + row * PITCH + pc * 16);
+        if (m < M && c < out_cols) *(u32x4*)(o + (long long)m * out_cols + c) = dc_stage_unswz(*(const u32x4*)(smem + row * PITCH + pc * 16), row);
     }
 }
 
