@@ -39,6 +39,9 @@ constexpr int KV_TILE = 64;                  // keys per iteration (two 32-key M
 // subtract-and-rescale pass is the exception, not the rule.  The d = 40 kernel is VALU-issue-bound (64 exps + 32 converts +
 // 16 max3 per 28 MFMAs and tile): the 32 packed FMAs this removes were ~13 % of its VALU time.
 constexpr float RESCALE_THR = 4.0f;
+#ifndef DC_ATTN_SOFTMAX_PRIO
+#define DC_ATTN_SOFTMAX_PRIO 2               // wave priority during the exp / convert block (0 = off: developer A/B)
+#endif
 #ifndef DC_ATTN_EARLY_STAGE
 #define DC_ATTN_EARLY_STAGE 1                // developer A/B switch: 0 = the next tile is written to LDS after the PV MFMAs
 #endif
@@ -263,6 +266,11 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
         }
     };
     auto softmax_part = [&](int t, bool first) {
+        // The exponentials run on the transcendental unit and do overlap the partner wave's MFMAs — but only if this wave wins
+        // the issue arbitration: at equal priority the (older) wave whose next instruction is an MFMA waiting for the matrix pipe
+        // holds the SIMD's issue slot, and the two waves' times add (tools/micro/mfma_valu_overlap.hip: v_exp beside MFMA 3.31 ms
+        // at equal priority = the sum, 1.97 ms = the max with the VALU wave at s_setprio 2; plain v_fma never overlaps).
+        if (DC_ATTN_SOFTMAX_PRIO) __builtin_amdgcn_s_setprio(DC_ATTN_SOFTMAX_PRIO);
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
             const float mloc = mloc_s[u];
@@ -325,6 +333,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             if (!ONES) l_run[u] += lsum;
         }
 
+        if (DC_ATTN_SOFTMAX_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     // ---- O^T += V^T . P^T ; A-operand element jj of lane-half lh is key 16*s2 + 8*(jj>>2) + 4*lh + (jj&3)
     // transposing read: lane (16-lane group g4, j16) addresses key row (j16>>2), d columns 4*(j16&3).. of its block
