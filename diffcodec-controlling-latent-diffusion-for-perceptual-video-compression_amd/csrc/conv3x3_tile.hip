@@ -69,10 +69,14 @@ __device__ __forceinline__ void wait_vmcnt()
 // are software-pipelined ACROSS K-steps in two half-steps (32 channels each): while the MFMAs of one half run, the reads of
 // the next half are in flight, with the workgroup barrier in the middle of the step (stage k+1 must be visible before its
 // first half is read).  A wave then never sits at the top of a step waiting for 18 reads with no MFMA to issue.
-template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST>
+// UPS (FAST only, no fused GroupNorm): the nearest-2x upsample of Upsample2D on the same pipeline — the halo is taken from the
+// low-resolution input ((TH/2 + 2) x 10 pixels), a tap's row offset is still an immediate, and its column offset ((x + kx - 1) >> 1)
+// takes one of three per-lane base addresses.
+template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
     static_assert(!FAST || NSTB == 2 || NSTB == 4, "the half-step pipeline indexes its weight ring with step & (NSTB - 1)");
+    static_assert(!UPS || (FAST && !GN), "the upsample form exists on the pipelined path, without GroupNorm on load");
     constexpr bool GENERIC = EPI == 0;
     const bool e_split = GENERIC && d.splitk > 1;
     const bool e_res = GENERIC ? (d.residual != nullptr && d.splitk <= 1) : EPI == 2;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * TM;                       // output rows per tile (tile is TH x 16 pixels)
     constexpr int BN = WN * TN * 16;
-    constexpr int HALO_MAX = (TM == 4 && !FAST) ? 200 : (TH + 2) * 18;   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
+    constexpr int HALO_MAX = UPS ? (TH / 2 + 2) * 10 : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
     constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
     constexpr int HP = FAST ? 160 : 128;              // halo pixel-row pitch (bytes)
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     }
 
     // ---- halo geometry (input coordinates).  upsample: output tile lives on the 2x grid, halo on the input grid
-    const int up = FAST ? 0 : d.upsample;
+    const int up = FAST ? (UPS ? 1 : 0) : d.upsample;
     const int HWd = up ? 10 : TW + 2;
     const int HHt = up ? TH / 2 + 2 : (dual ? 10 : (TH << sh) + 2);
     const int himg = HHt * HWd;                                 // halo pixels per image (dual: two images back to back)
@@ -317,7 +321,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     DC_NOW(ts0);
     if constexpr (FAST) {
         // ---- FAST main loop (see the kernel comment): half-step pipeline, taps unrolled, mid-step barrier
-        const int a_lane = ((wm * TM) * 18 + fr) * HP + (fq << 4);           // this lane's halo byte offset at tap (0,0), tm 0, half 0
+        // this lane's halo byte offset at tap (0,0), tm 0, half 0.  Upsample: output pixel (ty, x) reads low-resolution pixel
+        // (((ty + ky - 1) >> 1) + 1, ((x + kx - 1) >> 1) + 1) of the 10-wide halo: three column variants, rows stay immediates
+        int a_lane[UPS ? 3 : 1];
+        if constexpr (UPS) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a_lane[kx] = ((wm * TM / 2) * 10 + ((fr + kx - 1) >> 1) + 1) * HP + (fq << 4);
+        } else {
+            a_lane[0] = ((wm * TM) * 18 + fr) * HP + (fq << 4);
+        }
         int b_lane[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) b_lane[s] = H_BYTES + ((wn * TN) * 16 + fr) * 128 + (((4 * s + fq) ^ (fr & 7)) << 4);
@@ -325,7 +337,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         auto rd_half = [&](int tap, int s, int slot_off) {
             const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) xa[s][tm] = *(const bf16x8*)(sH + a_lane + ((tm + ky) * 18 + kx) * HP + s * 64);
+            for (int tm = 0; tm < TM; ++tm) {
+                if constexpr (UPS) xa[s][tm] = *(const bf16x8*)(sH + a_lane[kx] + ((((tm + ky + 1) >> 1)) * 10) * HP + s * 64);   // ((tm+ky-1)>>1)+1
+                else xa[s][tm] = *(const bf16x8*)(sH + a_lane[0] + ((tm + ky) * 18 + kx) * HP + s * 64);
+            }
             const char* bp = smem + b_lane[s] + slot_off;
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) wb[s][tn] = *(const bf16x8*)(bp + tn * 2048);
@@ -612,14 +627,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #endif
 }
 
-template <int TM, int TN, int NSTB, bool FAST = false>
+template <int TM, int TN, int NSTB, bool FAST = false, bool UPS = false>
 int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
     const int sh = d.Wo < 16 ? 1 : 0;
     const bool dual = sh && TM == 4;
     const int nblk = (dual ? d.N / 2 : d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh))) * dc_cdiv(d.Cout, BN);
-    constexpr int HALO_ROWS = (TM == 4 && !FAST) ? 200 : (TH + 2) * 18;
+    constexpr int HALO_ROWS = UPS ? (TH / 2 + 2) * 10 : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
 #ifdef DC_EXP_ONE_WG            // developer experiment: pad the allocation so one workgroup owns the CU
     const size_t lds = 96 * 1024;
@@ -629,7 +644,7 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
     const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
 #define DC_TILE_LAUNCH1(GN, EPI)                                                                                \
     do {                                                                                                        \
-        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST>;                                                    \
+        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST, (UPS && !GN)>;                                                    \
         static std::atomic<unsigned long long> attr_done{0};                                                    \
         dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
@@ -640,8 +655,12 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
         else if (epi == 2) DC_TILE_LAUNCH1(GN, 2);  \
         else DC_TILE_LAUNCH1(GN, 0);                \
     } while (0)
-    if (d.gn_ab) DC_TILE_LAUNCH(true);
-    else DC_TILE_LAUNCH(false);
+    if constexpr (UPS) {
+        DC_TILE_LAUNCH(false);                                  // (the dispatcher sends GroupNorm-on-load upsamples to the other form)
+    } else {
+        if (d.gn_ab) DC_TILE_LAUNCH(true);
+        else DC_TILE_LAUNCH(false);
+    }
 #undef DC_TILE_LAUNCH
 #undef DC_TILE_LAUNCH1
     return dc_launch_status();
@@ -709,6 +728,10 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
         }
         if (v == 4) return n160 ? launch_tile<4, 5, 2, true>(d, st) : launch_tile<4, 4, 2, true>(d, st);
         return n160 ? launch_tile<2, 5, 2, true>(d, st) : launch_tile<2, 4, 2, true>(d, st);
+    }
+    if (DC_CONV_FAST && d.upsample && !d.gn_ab && d.Wo >= 16 && (d.Cout & 7) == 0) {       // Upsample2D convs: the same pipeline
+        if (v == 4) return n160 ? launch_tile<4, 5, 2, true, true>(d, st) : launch_tile<4, 4, 2, true, true>(d, st);
+        return n160 ? launch_tile<2, 5, 2, true, true>(d, st) : launch_tile<2, 4, 2, true, true>(d, st);
     }
     if (v == 4 || v == 8) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);

@@ -139,6 +139,9 @@ CONV_CASES = [
     (2, 16, 16, 128, 0, 128, 3, 2, 1, False),       # stride 2
     (1, 16, 16, 64, 0, 64, 3, 2, 0, False),         # asymmetric pad (VAE encoder)
     (1, 8, 8, 64, 0, 128, 3, 1, 1, True),           # fused nearest-2x upsample
+    (2, 16, 16, 320, 0, 320, 3, 1, 1, True),        # Upsample2D conv on the pipelined path: 8-row tiles, 160-column tiles, four-slot ring
+    (20, 16, 24, 128, 0, 320, 3, 1, 1, True),       # the same with > 256 workgroups (two-slot ring), non-square map
+    (3, 10, 8, 192, 0, 256, 3, 1, 1, True),         # 4-row tiles (Ho = 20), 128-column tiles
     (2, 8, 8, 320, 0, 320, 1, 1, 1, False),         # 1x1
     (2, 64, 64, 320, 0, 320, 3, 1, 1, False),       # UNet 64x64 ResBlock conv (large tile path; <= 256 workgroups: four-slot weight ring)
     (10, 64, 64, 128, 64, 320, 3, 1, 1, False),     # the same path with > 256 workgroups: two-slot ring, two workgroups per CU, skip concat
