@@ -72,9 +72,12 @@ __device__ __forceinline__ void wait_vmcnt()
 // UPS (FAST only, no fused GroupNorm): the nearest-2x upsample of Upsample2D on the same pipeline — the halo is taken from the
 // low-resolution input ((TH/2 + 2) x 10 pixels), a tap's row offset is still an immediate, and its column offset ((x + kx - 1) >> 1)
 // takes one of three per-lane base addresses.
-template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST, bool UPS = false>
+// SH (FAST only, no fused GroupNorm): 8-wide maps — an MFMA row group covers two image rows of 8 pixels (and, with 8-row tiles, a
+// tile covers two whole 8x8 images); only the per-lane base address and the immediates differ.  Direct (unstaged) stores.
+template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST, bool UPS = false, bool SH = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
 {
+    static_assert(!SH || (FAST && !GN && !UPS), "the narrow-map form exists on the pipelined path, without GroupNorm on load");
     static_assert(!FAST || NSTB == 2 || NSTB == 4, "the half-step pipeline indexes its weight ring with step & (NSTB - 1)");
     static_assert(!UPS || (FAST && !GN), "the upsample form exists on the pipelined path, without GroupNorm on load");
     constexpr bool GENERIC = EPI == 0;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int WM = 2, WN = 2;
     constexpr int TH = WM * TM;                       // output rows per tile (tile is TH x 16 pixels)
     constexpr int BN = WN * TN * 16;
-    constexpr int HALO_MAX = UPS ? (TH / 2 + 2) * 10 : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
+    constexpr int HALO_MAX = UPS ? (TH / 2 + 2) * 10 : SH ? (TM == 4 ? 200 : ((TH << 1) + 2) * 10) : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
     constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
     constexpr int HP = FAST ? 160 : 128;              // halo pixel-row pitch (bytes)
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     const int Cin = d.C1 + d.C2;
     const int nchunks = Cin >> 6;
     // narrow maps (Wo == 8): the 16 lanes of an MFMA row cover 2 image rows of 8 pixels (sh = 1)
-    const int sh = FAST ? 0 : (d.Wo < 16 ? 1 : 0);
+    const int sh = FAST ? (SH ? 1 : 0) : (d.Wo < 16 ? 1 : 0);
     const int TW = 16 >> sh;
     // dual: 8x8 maps with the 8-row tile shape — one tile = TWO whole images (wave row wm = image), so the weight tile
     // streamed per K-step serves 128 pixels instead of 64 at the weight-bound 8x8 layers
@@ -327,6 +330,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         if constexpr (UPS) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) a_lane[kx] = ((wm * TM / 2) * 10 + ((fr + kx - 1) >> 1) + 1) * HP + (fq << 4);
+        } else if constexpr (SH) {
+            // narrow maps: lane fr -> pixel (fr >> 3, fr & 7) of the 10-wide halo; 8-row tiles: wave row wm = the second image
+            a_lane[0] = ((TM == 4 ? wm * 100 : (2 * wm * TM) * 10) + (fr >> 3) * 10 + (fr & 7)) * HP + (fq << 4);
         } else {
             a_lane[0] = ((wm * TM) * 18 + fr) * HP + (fq << 4);
         }
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 if constexpr (UPS) xa[s][tm] = *(const bf16x8*)(sH + a_lane[kx] + ((((tm + ky + 1) >> 1)) * 10) * HP + s * 64);   // ((tm+ky-1)>>1)+1
+                else if constexpr (SH) xa[s][tm] = *(const bf16x8*)(sH + a_lane[0] + ((2 * tm + ky) * 10 + kx) * HP + s * 64);
                 else xa[s][tm] = *(const bf16x8*)(sH + a_lane[0] + ((tm + ky) * 18 + kx) * HP + s * 64);
             }
             const char* bp = smem + b_lane[s] + slot_off;
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     // written out in 16-byte pieces, 20 lanes per 320-byte pixel row, instead of 8-byte pieces scattered over 16 rows per
     // store instruction (the epilogue was store-issue-bound: 15k cycles per workgroup against 1.2k per K-step).
     constexpr int SP = BN * 2 + 16;                              // staged row pitch (bytes)
-    constexpr bool stg = FAST && !GENERIC;                       // (the generic epilogue keeps its direct stores; the launcher
+    constexpr bool stg = FAST && !GENERIC && !SH;                     // (the generic epilogue keeps its direct stores; the launcher
                                                                  //  sends Cout % 8 != 0 to the other kernel)
     if constexpr (stg) {
         __builtin_amdgcn_sched_barrier(0);
@@ -627,14 +634,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #endif
 }
 
-template <int TM, int TN, int NSTB, bool FAST = false, bool UPS = false>
+template <int TM, int TN, int NSTB, bool FAST = false, bool UPS = false, bool SH = false>
 int launch_tile(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int TH = 2 * TM, BN = 2 * TN * 16;
     const int sh = d.Wo < 16 ? 1 : 0;
     const bool dual = sh && TM == 4;
     const int nblk = (dual ? d.N / 2 : d.N * (d.Ho / (TH << sh)) * (d.Wo / (16 >> sh))) * dc_cdiv(d.Cout, BN);
-    constexpr int HALO_ROWS = UPS ? (TH / 2 + 2) * 10 : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);
+    constexpr int HALO_ROWS = UPS ? (TH / 2 + 2) * 10 : SH ? (TM == 4 ? 200 : ((TH << 1) + 2) * 10) : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);
     const dim3 grid(nblk, d.splitk > 1 ? d.splitk : 1);
 #ifdef DC_EXP_ONE_WG            // developer experiment: pad the allocation so one workgroup owns the CU
     const size_t lds = 96 * 1024;
@@ -644,7 +651,7 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
     const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
 #define DC_TILE_LAUNCH1(GN, EPI)                                                                                \
     do {                                                                                                        \
-        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST, (UPS && !GN)>;                                                    \
+        auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST, (UPS && !GN), (SH && !GN)>;                                                    \
         static std::atomic<unsigned long long> attr_done{0};                                                    \
         dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
@@ -655,7 +662,7 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
         else if (epi == 2) DC_TILE_LAUNCH1(GN, 2);  \
         else DC_TILE_LAUNCH1(GN, 0);                \
     } while (0)
-    if constexpr (UPS) {
+    if constexpr (UPS || SH) {
         DC_TILE_LAUNCH(false);                                  // (the dispatcher sends GroupNorm-on-load upsamples to the other form)
     } else {
         if (d.gn_ab) DC_TILE_LAUNCH(true);
@@ -732,6 +739,10 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     if (DC_CONV_FAST && d.upsample && !d.gn_ab && d.Wo >= 16 && (d.Cout & 7) == 0) {       // Upsample2D convs: the same pipeline
         if (v == 4) return n160 ? launch_tile<4, 5, 2, true, true>(d, st) : launch_tile<4, 4, 2, true, true>(d, st);
         return n160 ? launch_tile<2, 5, 2, true, true>(d, st) : launch_tile<2, 4, 2, true, true>(d, st);
+    }
+    if (DC_CONV_FAST && d.Wo == 8 && !d.upsample && !d.gn_ab && (d.Cout & 7) == 0) {        // 8x8 maps: the same pipeline
+        if (v == 8) return n160 ? launch_tile<4, 5, 2, true, false, true>(d, st) : launch_tile<4, 4, 2, true, false, true>(d, st);
+        return n160 ? launch_tile<2, 5, 2, true, false, true>(d, st) : launch_tile<2, 4, 2, true, false, true>(d, st);
     }
     if (v == 4 || v == 8) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
