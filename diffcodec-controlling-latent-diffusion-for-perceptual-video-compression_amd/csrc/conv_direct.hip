@@ -6,6 +6,7 @@
 //     quant_conv): one wave per output pixel, lanes split the (tap, channel-vector) reduction.
 #include "dc_common.h"
 #include "../../include/diffcodec_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -72,6 +73,97 @@ __global__ __launch_bounds__(256) void conv3x3_nchw_f32_kernel(const float* __re
                 if (silu) v = dc_silu(v);
                 y[(((long long)n * Cout + co) * Ho + oy) * Wo + ox] = v;
             }
+        }
+    }
+}
+
+// Register-blocked form for strides 1 and 2 (round 2).  The kernel above gives a thread ONE pixel x 16 output channels and a
+// workgroup one input patch per 16 output channels: the staging of the patch (and, per (input channel, tap), four 16-byte LDS
+// weight reads for 16 FMAs) weighs as much as the arithmetic.  Here a thread owns FOUR consecutive pixels of a row x 16 output
+// channels (64 accumulators) and a workgroup is TROWS x TXG pixel-threads x CG output-channel groups sharing ONE input patch
+// (16 x 16 pixels x 64 channels as launched): 4x the FMAs per staged input value and per weight read.  The accumulation order
+// per output (input channels outer, taps inner) is unchanged.  160->320 at 64x64: 1.45 -> 0.96 ms, 64->64 at 128x128: 0.51 -> 0.34.
+template <int STRIDE, int TROWS, int TXG, int CG, int CI_T>
+__global__ __launch_bounds__(256) void conv3x3_nchw_f32_blk_kernel(const float* __restrict__ x, long long xbs,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                                   float* __restrict__ y, int Cin, int H, int W, int Cout,
+                                                                   int Ho, int Wo, int silu)
+{
+    static_assert(TROWS * TXG * CG == 256, "one pixel-thread x channel-group per thread");
+    constexpr int TW = TXG * 4;                         // output tile width
+    constexpr int PH = TROWS * STRIDE + 2, PW = TW * STRIDE + 2;
+    constexpr int NC = 3 * STRIDE + 3;                  // input columns a thread needs per row
+    constexpr int COT = CG * 16;                        // output channels per workgroup
+    __shared__ float s_in[CI_T][PH][PW + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[CI_T][9][COT];
+    const int tiles_x = (Wo + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TROWS;
+    const int co0 = blockIdx.y * COT;
+    const int n = blockIdx.z;
+    const int cg = threadIdx.x / (TROWS * TXG), pt = threadIdx.x % (TROWS * TXG);
+    const int ty = pt / TXG, tx = pt % TXG;
+    const int oy = ty0 + ty, ox = tx0 + tx * 4;
+    float acc[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+    const int ix0 = tx0 * STRIDE - 1, iy0 = ty0 * STRIDE - 1;
+    for (int c0 = 0; c0 < Cin; c0 += CI_T) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CI_T * PH * PW; i += 256) {
+            const int px = i % PW, py = (i / PW) % PH, ci = i / (PW * PH);
+            const int gx = ix0 + px, gy = iy0 + py, c = c0 + ci;
+            float v = 0.f;
+            if (c < Cin && gx >= 0 && gx < W && gy >= 0 && gy < H) v = x[n * xbs + ((long long)c * H + gy) * W + gx];
+            s_in[ci][py][px] = v;
+        }
+        for (int i = threadIdx.x; i < CI_T * 9 * COT; i += 256) {
+            const int co = i % COT, tap = (i / COT) % 9, ci = i / (COT * 9);
+            float v = 0.f;
+            if (c0 + ci < Cin && co0 + co < Cout) v = w[(((long long)(co0 + co)) * Cin + (c0 + ci)) * 9 + tap];
+            s_w[ci][tap][co] = v;
+        }
+        __syncthreads();
+#pragma unroll 1                                        // (unrolled, hipcc keeps several channels' windows and weights live: 256 VGPRs)
+        for (int ci = 0; ci < CI_T; ++ci) {
+            float in[3][NC];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) in[r][c] = s_in[ci][ty * STRIDE + r][tx * 4 * STRIDE + c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 wv = *(const f32x4*)&s_w[ci][t][cg * 16 + 4 * g];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[p][4 * g + r] += in[t / 3][p * STRIDE + t % 3] * wv[r];
+                }
+            }
+        }
+    }
+    if (oy >= Ho || ox >= Wo) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int co = co0 + cg * 16 + i;
+        if (co >= Cout) break;
+        const float b = bias ? bias[co] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            v[p] = acc[p][i] + b;
+            if (silu) v[p] = dc_silu(v[p]);
+        }
+        float* dst = y + (((long long)n * Cout + co) * Ho + oy) * Wo + ox;
+        if (ox + 3 < Wo && (Wo & 3) == 0) {
+            *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (ox + p < Wo) dst[p] = v[p];
         }
     }
 }
@@ -245,8 +337,17 @@ extern "C" int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, con
 {
     if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2 && stride != 4)) return DC_ERR_INVALID;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    const dim3 grid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, CO_T), N);
     hipStream_t st = (hipStream_t)stream;
+    // the register-blocked form (16 x 16 pixels x 64 output channels per workgroup) wins where there are >= 64 output channels to
+    // share an input patch and the map is at least 64 wide (or 32 wide with >= 160 channels); measured per shape, tools/bench_f32conv.py
+    static const int blk = getenv("DC_F32CONV_BLOCKED") ? atoi(getenv("DC_F32CONV_BLOCKED")) : 1;     // developer A/B knob
+    if (blk && stride != 4 && Cout >= 64 && (Wo >= 64 || (Wo >= 32 && Cout >= 160))) {
+        const dim3 bgrid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, 64), N);
+        if (stride == 1) hipLaunchKernelGGL((conv3x3_nchw_f32_blk_kernel<1, 16, 4, 4, 8>), bgrid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+        else hipLaunchKernelGGL((conv3x3_nchw_f32_blk_kernel<2, 16, 4, 4, 8>), bgrid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
+        return dc_launch_status();
+    }
+    const dim3 grid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, CO_T), N);
     if (stride == 1) hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<1, 8>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
     else if (stride == 2) hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<2, 8>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);
     else hipLaunchKernelGGL((conv3x3_nchw_f32_kernel<4, 2>), grid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);

@@ -114,7 +114,10 @@ def test_fuse_warped(ops):
 @pytest.mark.parametrize("cin,cout,hw,stride,silu", [(3, 16, 40, 1, True), (16, 32, 33, 2, True), (64, 160, 16, 2, True),
                                                       (160, 64, 8, 1, True), (64, 1, 8, 1, False), (80, 160, 8, 1, False),
                                                       # larger maps: ragged tiles, Cout < 16, stride 2
-                                                      (3, 16, 70, 1, True), (20, 40, 67, 2, False), (16, 1, 64, 1, False)])
+                                                      (3, 16, 70, 1, True), (20, 40, 67, 2, False), (16, 1, 64, 1, False),
+                                                      # the register-blocked form (>= 64 output channels, wide maps): ragged map,
+                                                      # ragged channel tile, stride 2 at 34 wide with 160 channels
+                                                      (32, 64, 70, 1, True), (16, 80, 64, 1, False), (24, 160, 67, 2, False)])
 def test_conv3x3_nchw_f32(ops, cin, cout, hw, stride, silu):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, cin + 2, hw, hw, generator=g)
