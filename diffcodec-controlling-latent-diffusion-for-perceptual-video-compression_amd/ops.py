@@ -264,10 +264,13 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
 # tile (Cout <= 160).  With more N-tiles every workgroup of a pixel tile would redo the same exp/rcp work (Cout/160 x
 # the 1.4x halo overlap); one HBM-bound elementwise pass (which also resolves the skip concat) is cheaper.
 FUSE_GN_MAX_COUT = int(__import__("os").environ.get("DC_FUSE_GN_MAX_COUT", "160"))
+# ... except at model batches of at most this many samples (one- and two-frame decodes), where every launch is latency-bound and
+# the separate pass costs a launch of its own: fused everywhere, 175 -> 170 ms per single frame
+FUSE_GN_SMALL_BATCH = int(__import__("os").environ.get("DC_FUSE_GN_SMALL_BATCH", "4"))
 
 
 def conv_gn_silu(x, pc, ab, x2=None, **kw):
-    if pc.kind == "igemm" and pc.ksize == 3 and pc.cout > FUSE_GN_MAX_COUT:
+    if pc.kind == "igemm" and pc.ksize == 3 and pc.cout > FUSE_GN_MAX_COUT and x.shape[0] > FUSE_GN_SMALL_BATCH:
         return conv(gn_apply(x, ab, silu=True, x2=x2), pc, **kw)
     return conv(x, pc, x2=x2, gn_ab=ab, gn_silu=True, **kw)
 
