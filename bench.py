@@ -11,8 +11,12 @@ checkpoint is reachable offline), bf16 compute with fp32 accumulation.
   --config c2 (default)  BASELINE configs[1]: 512x512 frames, one DualFlowControlNet (the configuration `metric` is quoted on)
   --config c4            BASELINE configs[3]: 960x512 frames = two 512x512 windows each, GOP-4, DualFlowControlNet +
                          ResControlNet (warp_cond); frames/s counts whole 960x512 frames
+  --config validation    what validation.py:37,106,132-146 runs: UniPC multistep, 40 steps, FreeU, CFG; not the headline either
 N > 1: one process per GPU (torch.distributed / RCCL); units are sharded across ranks with no data-path collective; rank 0
 synthesises the weights and broadcasts the packed tensors once (outside the timed region).  Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with no launcher around it starts its own N ranks (child processes, before this process makes any
+GPU call); under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.  The timed step is the decode of this rank's
+units only — decoded frames stay on the rank that decoded them; the optional uint8 gather is timed separately (`gather_ms`).
 """
 import argparse
 import json
@@ -23,7 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+torch = None          # imported in main(), after the self-launch decision: the launching parent never touches the GPU
 
 STEPS_DDIM = 20
 SIZE = 512
@@ -89,31 +93,66 @@ def cpu_baseline(sds, threads, device_decode=None):
 
 
 # PMC reference shape per kernel family (tools/pmc_conv.py launches exactly these; algorithmic bytes = inputs + weights + output)
-PMC_SHAPES = {"gemm_dma_kernel": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320)", 167976960),
-              "conv3x3_tile_kernel": ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360),
-              "attn_kernel": ("attention B=32 H=8 N=4096 d=40", 335544320)}
+# value: (shape label, algorithmic bytes, launch grid in threads of that shape — what tells a family's PMC rows apart)
+PMC_SHAPES = {"gemm_dma_kernel": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320)", 167976960, 524288),
+              "conv3x3_tile_kernel": ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360, 524288),
+              "attn_kernel": ("attention B=32 H=8 N=4096 d=40", 335544320, 1048576)}
+PMC_FILES = ("r03_pmc_summary.json", "r02_pmc_summary.json")
 
 
 def latest_pmc(family):
     """HBM traffic per launch of the family's PMC reference shape, from the committed rocprofv3 --pmc passes (hardware counters
     cannot be read in-process): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the gfx950 note of the guide."""
     key = next((k for k in PMC_SHAPES if k in family), None)
-    for name in ("r02_pmc_summary.json",):
+    for name in PMC_FILES:
         p = os.path.join(ROOT, "profiles", name)
         if key is None or not os.path.exists(p):
             continue
         with open(p) as fh:
             summ = json.load(fh)
-        rows = [v for k, v in summ.items() if key in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        shape, alg, grid = PMC_SHAPES[key]
+        rows = [v for k, v in summ.items() if key in k and k.endswith(f"grid={grid}") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
         if not rows:
             continue
-        r = rows[0]                                  # first launch group of the family = the reference shape
+        r = rows[0]                                  # the launch group whose grid is the reference shape's
         hbm = int((2 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024)
-        shape, alg = PMC_SHAPES[key]
         return hbm, (f"HBM bytes per launch of {shape}: (2*FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes "
                      f"(profiles/{name}) = {hbm / alg:.3f}x its algorithmic {alg} B; `achieved` is the family aggregate over all of "
                      f"its shapes in one step")
     return None, "no PMC summary committed for this kernel family"
+
+
+def self_launch(n):
+    """`--gpus n` without a launcher: n ranks as child processes of this one (the shape of train_control.sh:19's
+    `accelerate launch --num_processes 8`).  Called before torch is imported here, so the parent never initialises the GPU;
+    children are fresh interpreters (no exec of a GPU-touching process).  Rank 0's stdout (the JSON line) is this process's
+    stdout; the exit code is non-zero if any rank fails, and the surviving ranks of a failed job are terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"rank {procs.index(p)} exited with code {code}: stopping the other ranks")
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.2)
+    sys.exit(rc)
 
 
 def main():
@@ -129,13 +168,20 @@ def main():
     ap.add_argument("--dual-stream", type=int, default=1, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the post-timing legs (profiling runs)")
+    ap.add_argument("--c3-batch", type=int, default=22, help="units per pipe call of the strong-scaling C3 pass")
+    ap.add_argument("--shapes-out", default=None, help="write the in-situ per-shape launch table of the roofline leg to this file")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)                                  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ.get('WORLD_SIZE')}: refusing to report "
+                 f"a {os.environ.get('WORLD_SIZE', 1)}-rank run as an {args.gpus}-GPU number")
+    global torch
+    import torch
 
     from diffcodec_amd import clip_decode as CD, lib, sharding
     from diffcodec_amd.synthetic import synth_text
     rank, local, world = sharding.init_from_env()
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
     if os.environ.get("DC_FORCE_DEVICE") is not None:      # rehearsal of the N>1 path on a 1-GPU box (with DC_DIST_BACKEND=gloo)
         local = int(os.environ["DC_FORCE_DEVICE"])
     torch.cuda.set_device(local)
@@ -200,6 +246,53 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+
+    # ---- the optional exchange, timed on its own (never part of `value`): uint8 gather of one step's units onto rank 0
+    gather_ms = None
+    if world > 1:
+        u8 = CD.units_to_u8(out)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        allu = CD.gather_units(u8, all_units, rank, world)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = round((time.perf_counter() - t1) * 1e3, 3)
+        assert (allu is not None and allu.shape[0] == F * world) if rank == 0 else allu is None
+        del allu, u8
+
+    # ---- BASELINE configs[2] as a STRONG-scaling job (every rank takes part): one 97-frame GOP-12 clip = 88 inter-frame units
+    #      dealt round-robin over the ranks (11 per rank at 8 ranks), decoded in batches of at most --c3-batch units
+    c3 = None
+    if not c4 and not args.no_roofline and args.config == "c2":
+        units3 = CD.plan_units(97, 12, SIZE, SIZE)
+        mine3 = CD.shard(units3, rank, world)
+        b3 = max(1, min(args.c3_batch, len(mine3)))
+        while len(mine3) % b3:                                   # equal batches: one captured graph shape per rank
+            b3 -= 1
+        fpn3 = sorted({(u.frame, u.prev, u.next) for u in mine3})
+        src3 = CD.ResidentSource(CD.SyntheticSource(SIZE, SIZE, device=device, seed=977), fpn3,
+                                 noise={f: CD.frame_noise(f, SIZE, SIZE, 99).to(device) for f, _, _ in fpn3})
+        run3 = lambda: CD.decode_units(pipe, mine3, src3, pe, npe, batch=b3, frame_size=(SIZE, SIZE), **kw)
+        run3()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        o3 = run3()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        d3 = time.perf_counter() - t1
+        assert torch.isfinite(o3).all() and o3.shape[0] == len(mine3)
+        if world > 1:
+            tm = torch.tensor([d3], device=device, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            d3 = tm.item()
+        c3 = dict(scaling="strong", units=len(units3), units_per_rank=len(mine3), batch=b3, seconds=round(d3, 4),
+                  frames_per_s=round(len(units3) / d3, 3),
+                  note="BASELINE configs[2]: the 88 inter frames of one 97-frame GOP-12 clip at 512x512, sharded round-robin over the ranks")
+        del o3, src3
 
     extras = rank == 0 and not args.no_roofline
 
@@ -284,8 +377,9 @@ def main():
         summ = timer.summary()
         tot_ms = sum(f["ms"] for f in summ.values())
         families = []
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "kernel_shapes.txt"), "w") as fh:
+        if args.shapes_out:
+            os.makedirs(os.path.dirname(os.path.abspath(args.shapes_out)) or ".", exist_ok=True)
+        with open(args.shapes_out or os.devnull, "w") as fh:
             fh.write("# in-situ launch durations of one eager step (HIP events on the launch stream), per kernel family and shape\n")
             for fam, f in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                 tfl = f["flops"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] else 0.0
@@ -339,7 +433,8 @@ def main():
                        "parallelism": f"unit-shard x{world}", "backend": backend_name, "backend_world_size": backend_world},
             "frame_tflop_algorithmic": None if c4 else round(TFLOP_PER_FRAME, 2),
             "frame_mfma_frac": None if c4 else round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
-            "single_frame": single, "gop12_batch": gop12, "unet_forward": unet_fwd, "vae_encode": vae_enc,
+            "single_frame": single, "gop12_batch": gop12, "c3_clip_strong": c3, "gather_ms": gather_ms,
+            "unet_forward": unet_fwd, "vae_encode": vae_enc,
             "roofline": roof, "kernel_families": families, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

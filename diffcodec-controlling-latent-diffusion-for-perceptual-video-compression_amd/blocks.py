@@ -4,8 +4,6 @@ re-expressed as sequences of C-ABI launches on NHWC bf16 activations.  Host code
 
 Weight keys are the diffusers state-dict keys; topology follows the published SD-1.5 modules
 as called from controlnet/flownet.py:74-124 and pipeline.py:358-367."""
-import os
-
 import torch
 
 from . import ops
@@ -15,11 +13,18 @@ from .ops import PackedConv
 # Transformer2DModel.norm + proj_in: GroupNorm is applied by its own HBM-bound pass and the 1x1 runs on the LDS-DMA GEMM, whose
 # epilogue also writes the LayerNorm row statistics norm1 needs.  The alternative (GroupNorm affine inside the gather GEMM's load
 # stage + a separate row-statistics pass) was the round-1 choice above 65,536 rows; measured again in round 2 on one box it costs
-# +5.5 ms per 16-frame step (igemm 26 -> 14 ms against +3.5 ms gn_apply and +5.8 ms GEMM).  DC_PROJ_IN_FUSE_MIN_ROWS re-enables it (A/B).
-PROJ_IN_FUSE_MIN_ROWS = int(os.environ.get("DC_PROJ_IN_FUSE_MIN_ROWS", str(1 << 62)))
+# +5.5 ms per 16-frame step (igemm 26 -> 14 ms against +3.5 ms gn_apply and +5.8 ms GEMM).  Module constant (tools assign it for an A/B);
+# nothing here reads the environment.
+PROJ_IN_FUSE_MIN_ROWS = 1 << 62
 # LayerNorm folded into the following linear's weights + epilogue (ops.PackedConv(ln=...)): removes the three standalone
-# LayerNorm passes of every BasicTransformerBlock.  DC_LN_FOLD=0 keeps the separate dc_layernorm_bf16 launches (A/B).
-LN_FOLD = os.environ.get("DC_LN_FOLD", "1") != "0"
+# LayerNorm passes of every BasicTransformerBlock.  False keeps the separate dc_layernorm_bf16 launches (A/B from tools/).
+LN_FOLD = True
+
+
+# Captured hipGraphs hold raw addresses of the step-invariant buffers the modules cache (cross-attention K/V of the text, FDN
+# gamma/beta).  The modules refill those buffers IN PLACE while the shape stays the same; whenever one has to be re-allocated
+# (another batch size) this epoch moves on, and the pipeline drops its graphs when it sees a new value.
+BUFFER_EPOCH = [0]
 
 
 def _f32(sd, key, device):
@@ -119,6 +124,7 @@ class TransformerBlock:
             self.kv_ctx.copy_(new)          # keep the address stable for captured hipGraphs
         else:
             self.kv_ctx = new
+            BUFFER_EPOCH[0] += 1
 
     def __call__(self, x, cfg_shared=False):
         """cfg_shared: x is ONE half [B] of a classifier-free-guidance batch whose two halves are identical up to here

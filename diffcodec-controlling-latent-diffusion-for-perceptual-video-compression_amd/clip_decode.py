@@ -15,7 +15,10 @@ BASELINE configs 3-5 are this driver with different parameters:
 
 Units are independent: there is NO data-path collective.  The only collective here is the optional
 gather of decoded units onto one rank (`gather=True`), needed when the tiles of one frame were decoded on different ranks
-and must be blended.  Trailing-frame policy: an inter frame needs a closing anchor, so frames after the last intra frame
+and must be blended.  What is gathered are the units as uint8 IMAGES (0.79 MB per 512x512 unit, one padded tensor
+`dist.gather`, no pickling): the reference's notebook also blends the tiles as the 8-bit images `pipe(...)` returned
+(patch_exp.ipynb cell 7), so a unit is quantised before the blend on every path and a sharded decode equals the
+single-rank one bit for bit.  Trailing-frame policy: an inter frame needs a closing anchor, so frames after the last intra frame
 are not decodable bidirectionally; `sharding.gop_inter_frames` drops them (the reference's `get_inter_frames` merely
 counts them for metrics).  `trailing_frames()` reports which frames were dropped."""
 import os
@@ -133,12 +136,19 @@ def frame_noise(frame, height, width, seed, channels=4):
 
 @torch.no_grad()
 def decode_units(pipe, units, source, prompt_embeds, negative_prompt_embeds=None, *, batch=16, seed=0, frame_size=None,
-                 output="pt", **pipe_kwargs):
+                 output="pt", unit_hw=(512, 512), **pipe_kwargs):
     """Decode `units` (this rank's share) `batch` at a time.  Returns fp32 [len(units), 3, th, tw] in [0,1] on the device
     (output='pt') or the latents (output='latent').  Controls of a frame are loaded once and cropped per window; flows keep
-    frame units (patch_exp.ipynb does not re-base them)."""
+    frame units (patch_exp.ipynb does not re-base them).  An empty share (more ranks than units) returns an empty tensor
+    of the same trailing shape, so callers can concatenate / gather rank outputs without a special case."""
     if not units:
-        return torch.empty((0,), device=pipe.device)
+        th, tw = unit_hw
+        shape = (0, 4, th // 8, tw // 8) if output == "latent" else (0, 3, th, tw)
+        return torch.empty(shape, device=pipe.device, dtype=torch.float32)
+    for name, t in (("prompt_embeds", prompt_embeds), ("negative_prompt_embeds", negative_prompt_embeds)):
+        if t is not None and t.shape[0] != 1 and t.shape[0] < min(batch, len(units)):
+            raise ValueError(f"{name} has batch {t.shape[0]}: pass one row (shared by every unit) or at least one per unit "
+                             f"of a chunk ({min(batch, len(units))})")
     cache = {}
 
     def frame_inputs(u):
@@ -175,32 +185,50 @@ def decode_units(pipe, units, source, prompt_embeds, negative_prompt_embeds=None
     return torch.cat(outs, 0).contiguous()
 
 
-def gather_units(local, my_units, num_units, dst=0):
-    """Collect per-unit tensors [n_local, ...] on `dst` in unit order (optional; see module docstring)."""
-    ids = [u.uid for u in my_units]
-    if not torch.distributed.is_available() or not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
-        out = torch.empty((num_units,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        out[ids] = local
-        return out
+def units_to_u8(images):
+    """fp32 unit images [n,3,th,tw] in [0,1] -> uint8 [n,th,tw,3]: `image_processor.postprocess(output_type='pil')`'s
+    quantisation (pipeline.py:397-398: x * 255, round, uint8), applied to the tensor on whatever device it lives."""
+    return (images.permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
+
+
+def gather_units(local_u8, units, rank=None, world=None, mode="unit", dst=0):
+    """Collect this rank's uint8 unit images [n_local, th, tw, 3] on `dst` as [len(units), th, tw, 3] in unit order.  Every
+    rank can list every other rank's share (`shard` is a pure function), so only pixels travel: ONE `dist.gather` of
+    tensors padded to the largest share — device tensors over RCCL, host tensors over gloo (which gathers on the CPU
+    only).  Returns None on the other ranks."""
     import torch.distributed as dist
-    world, rank = dist.get_world_size(), dist.get_rank()
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object((ids, local.cpu()), gathered, dst=dst)          # ragged shares: object gather (decoded frames only)
+    ini = dist.is_available() and dist.is_initialized()
+    if rank is None or world is None:
+        rank, world = (dist.get_rank(), dist.get_world_size()) if ini else (0, 1)
+    shares = [[u.uid for u in shard(units, r, world, mode)] for r in range(world)]
+    if local_u8.dtype != torch.uint8 or local_u8.shape[0] != len(shares[rank]):
+        raise ValueError("gather_units takes this rank's uint8 unit images, one per unit of its share")
+    if world == 1 or not ini:
+        out = torch.empty((len(units),) + tuple(local_u8.shape[1:]), dtype=torch.uint8, device=local_u8.device)
+        out[shares[rank]] = local_u8
+        return out
+    send = local_u8 if dist.get_backend() != "gloo" else local_u8.cpu()
+    per = max(len(s_) for s_ in shares)
+    pad = torch.zeros((per,) + tuple(send.shape[1:]), dtype=torch.uint8, device=send.device)
+    pad[:send.shape[0]] = send
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
     if rank != dst:
         return None
-    out = torch.empty((num_units,) + tuple(local.shape[1:]), dtype=local.dtype)
-    for r_ids, r_t in gathered:
-        if len(r_ids):
-            out[r_ids] = r_t
+    out = torch.empty((len(units),) + tuple(pad.shape[1:]), dtype=torch.uint8, device=pad.device)
+    for r in range(world):
+        if shares[r]:
+            out[shares[r]] = bufs[r][:len(shares[r])]
     return out
 
 
-def blend_frames(unit_images, units, height, width, overlap=64):
-    """fp32 unit images [n,3,th,tw] in [0,1] of COMPLETE frames -> {frame: uint8 [H,W,3]} (device blend kernel when the
-    tensors live on the GPU, `tiling.merge_ramp` on the host otherwise)."""
-    import numpy as np
-
+def blend_frames(unit_u8, units, height, width, overlap=64):
+    """uint8 unit images [n,th,tw,3] of COMPLETE frames -> {frame: uint8 [H,W,3]} (device blend kernel when the tensor
+    lives on the GPU, `tiling.merge_ramp` on the host otherwise; both blend the 8-bit tiles in fp32 with the same op
+    order, so the two are bit-identical)."""
     from . import ops, tiling
+    if unit_u8.dtype != torch.uint8:
+        raise ValueError("blend_frames takes uint8 unit images (units_to_u8)")
     frames = {}
     by_frame = {}
     for k, u in enumerate(units):
@@ -209,14 +237,14 @@ def blend_frames(unit_images, units, height, width, overlap=64):
         lst.sort()
         idx = [k for _, k, _ in lst]
         coords = [w for _, _, w in lst]
-        tiles = unit_images[idx].contiguous()
+        tiles = unit_u8[idx]
         if len(lst) == 1 and coords[0] == (0, height, 0, width):
-            frames[f] = (tiles[0].permute(1, 2, 0) * 255.0).round().clamp(0, 255).to(torch.uint8).cpu().numpy()
+            frames[f] = tiles[0].cpu().numpy()
         elif tiles.is_cuda:
-            frames[f] = ops.blend_tiles_ramp(tiles, coords, (height, width), overlap).cpu().numpy()
+            frames[f] = ops.blend_tiles_ramp(tiles.permute(0, 3, 1, 2).float().contiguous(), coords, (height, width), overlap,
+                                             scale=1.0).cpu().numpy()
         else:
-            host = [np.asarray(t.permute(1, 2, 0).numpy() * 255.0, np.float32) for t in tiles]
-            frames[f] = tiling.merge_ramp(host, coords, (height, width), order="hwc", feather=overlap)
+            frames[f] = tiling.merge_ramp([t.numpy() for t in tiles], coords, (height, width), order="hwc", feather=overlap)
     return frames
 
 
@@ -231,11 +259,13 @@ def decode_clip(pipe, source, num_frames, gop_size, height, width, prompt_embeds
         world = torch.distributed.get_world_size() if ini else 1
     units = plan_units(num_frames, gop_size, height, width, tile, overlap)
     mine = shard(units, rank, world, shard_mode)
+    unit_hw = (height, width) if (height, width) == (tile, tile) else (tile, tile)
     images = decode_units(pipe, mine, source, prompt_embeds, negative_prompt_embeds, batch=batch, seed=seed,
-                          frame_size=(height, width), **pipe_kwargs)
+                          frame_size=(height, width), unit_hw=unit_hw, **pipe_kwargs)
+    u8 = units_to_u8(images)
     frames = None
     if gather and world > 1:
-        allimg = gather_units(images, mine, len(units), dst=0)
+        allimg = gather_units(u8, units, rank, world, shard_mode, dst=0)
         if rank == 0:
             frames = blend_frames(allimg, units, height, width, overlap)
     else:
@@ -247,5 +277,5 @@ def decode_clip(pipe, source, num_frames, gop_size, height, width, prompt_embeds
             have[u.frame] = have.get(u.frame, 0) + 1
         complete = [k for k, u in enumerate(mine) if have[u.frame] == per_frame[u.frame]]
         if complete:
-            frames = blend_frames(images[complete], [mine[k] for k in complete], height, width, overlap)
+            frames = blend_frames(u8[complete], [mine[k] for k in complete], height, width, overlap)
     return dict(units=units, mine=mine, images=images, frames=frames)

@@ -15,7 +15,7 @@ from types import SimpleNamespace
 
 import torch
 
-from . import ops, weights
+from . import blocks, ops, weights
 from .blocks import EncoderHalf
 from .ops import PackedConv, PackedConvF32
 from .unet import as_nchw, to_nhwc_bf16
@@ -123,7 +123,8 @@ class HipDualFlowControlNet:
     def prepare_controls(self, controlnet_cond, flow_cond, warp_cond=None):
         """Pyramid + FDN gamma/beta (control_utils.py:31-32) at the controls' own batch size; cached by identity
         (pointer, shape and in-place version of EVERY control tensor, `warp_cond` of the ResControlNet included).  The
-        gamma/beta buffers keep their addresses across calls (captured hipGraphs read them)."""
+        gamma/beta buffers keep their addresses while the batch shape stays the same (captured hipGraphs read them); a
+        re-allocation bumps `blocks.BUFFER_EPOCH`, which makes the pipeline drop its graphs."""
         key = tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (controlnet_cond, flow_cond, warp_cond) if t is not None)
         if key == self._ctrl_key:
             return self.gamma_beta
@@ -139,6 +140,7 @@ class HipDualFlowControlNet:
                 o[1].copy_(n[1])
         else:
             self.gamma_beta = gb
+            blocks.BUFFER_EPOCH[0] += 1
         self._ctrl_key = key
         self._ctrl_keepalive = (controlnet_cond, flow_cond, warp_cond)
         return self.gamma_beta

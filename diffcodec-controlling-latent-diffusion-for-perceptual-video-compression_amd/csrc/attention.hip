@@ -589,8 +589,8 @@ template <int D>
 int launch(const AttnArgs& a, hipStream_t st)
 {
     // two query blocks per wave only for the small heads (register budget) and only when that still leaves >= 2 workgroups per CU
-    static const int force_qb = getenv("DC_ATTN_QB") ? atoi(getenv("DC_ATTN_QB")) : 0;      // developer knob
-    static const int no_short = getenv("DC_ATTN_NO_SHORT") ? atoi(getenv("DC_ATTN_NO_SHORT")) : 0;   // developer knob (A/B)
+    static const int force_qb = DC_KNOB("DC_ATTN_QB", 0);      // developer knob
+    static const int no_short = DC_KNOB("DC_ATTN_NO_SHORT", 0);   // developer knob (A/B)
     // short context (text cross-attention): keys resident, several query blocks per workgroup — when enough workgroups remain
     const bool short_ctx = !no_short && a.Nk <= 2 * KV_TILE;
     if constexpr (D <= 48) {          // d = 80 spills at two blocks per wave (measured slower)
@@ -598,7 +598,7 @@ int launch(const AttnArgs& a, hipStream_t st)
         if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) {
             if (short_ctx && wgs2 / SHORT_PASSES >= 512) return launch_qb<D, 2, true>(a, st);
             // long context with at least one 8-wave workgroup per CU: the ping-pong form (DC_ATTN_PP=0/1: developer A/B knob)
-            static const int force_pp = getenv("DC_ATTN_PP") ? atoi(getenv("DC_ATTN_PP")) : -1;
+            static const int force_pp = DC_KNOB("DC_ATTN_PP", -1);
             const long long wgs_pp = (long long)a.B * a.heads * ((a.Nq + 511) / 512);
             if (!short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
                 if ((a.Nk % KV_TILE) != 0) return launch_qb_r<D, 2, false, true, true>(a, st);

@@ -690,7 +690,7 @@ int dc_conv3x3_tile_supported(const dc_conv_desc& d)
 // workgroups per CU where the 160-column tile has room for two stages only.
 static bool use_n160(const dc_conv_desc& d)
 {
-    static const int force128 = getenv("DC_CONV_BN128") ? atoi(getenv("DC_CONV_BN128")) : 0;
+    static const int force128 = DC_KNOB("DC_CONV_BN128", 0);
     return d.Cout % 160 == 0 && !(force128 && d.Cout % 128 == 0);
 }
 
@@ -726,7 +726,7 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
     const int v = tile_variant(d);
     if (DC_CONV_FAST && !d.upsample && d.Wo >= 16 && (d.Cout & 7) == 0) {            // plain maps: half-step pipeline (see the kernel comment)
         // at most one workgroup per CU (one- or two-frame decodes): a four-slot weight ring, three taps of weights in flight
-        static const int deep = getenv("DC_CONV_DEEP") ? atoi(getenv("DC_CONV_DEEP")) : 1;      // developer A/B knob
+        static const int deep = DC_KNOB("DC_CONV_DEEP", 1);      // developer A/B knob
         const int th = v == 4 ? 8 : 4, bn = n160 ? 160 : 128;
         const long long wgs = (long long)d.N * (d.Ho / th) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
         if (deep && wgs <= 256) {

@@ -340,7 +340,7 @@ extern "C" int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, con
     hipStream_t st = (hipStream_t)stream;
     // the register-blocked form (16 x 16 pixels x 64 output channels per workgroup) wins where there are >= 64 output channels to
     // share an input patch and the map is at least 64 wide (or 32 wide with >= 160 channels); measured per shape, tools/bench_f32conv.py
-    static const int blk = getenv("DC_F32CONV_BLOCKED") ? atoi(getenv("DC_F32CONV_BLOCKED")) : 1;     // developer A/B knob
+    static const int blk = DC_KNOB("DC_F32CONV_BLOCKED", 1);     // developer A/B knob
     if (blk && stride != 4 && Cout >= 64 && (Wo >= 64 || (Wo >= 32 && Cout >= 160))) {
         const dim3 bgrid(dc_cdiv(Wo, 16) * dc_cdiv(Ho, 16), dc_cdiv(Cout, 64), N);
         if (stride == 1) hipLaunchKernelGGL((conv3x3_nchw_f32_blk_kernel<1, 16, 4, 4, 8>), bgrid, dim3(256), 0, st, x, x_batch_stride, w, bias, y, Cin, H, W, Cout, Ho, Wo, silu);

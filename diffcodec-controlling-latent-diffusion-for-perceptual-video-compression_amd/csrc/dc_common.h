@@ -19,6 +19,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define DC_WAVE 64
 
+// Developer A/B switches of the launchers (tile shape, ring depth, kernel selection).  The product library is built WITHOUT
+// DC_DEV_KNOBS, so every DC_KNOB folds to its default and no dispatch decision depends on the environment; scratch builds of
+// tools/ (-DDC_DEV_KNOBS) read the variable once.
+#ifdef DC_DEV_KNOBS
+#include <cstdlib>
+#define DC_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define DC_KNOB(name, dflt) (dflt)
+#endif
+
 __device__ __forceinline__ float dc_bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t dc_f2bf(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 

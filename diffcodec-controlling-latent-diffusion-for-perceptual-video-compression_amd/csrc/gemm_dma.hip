@@ -565,12 +565,12 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     const long long big = ((M + 127) / 128) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
     // 2 LDS stages for the big tiles keep two workgroups resident per CU (2 waves per SIMD: one computes while the
     // other waits for its DMA); the small tiles afford 3 stages at the same residency.
-    static const int force_nst = getenv("DC_GEMM_NST") ? atoi(getenv("DC_GEMM_NST")) : 0;   // developer knobs
-    static const int force_small = getenv("DC_GEMM_SMALL") ? atoi(getenv("DC_GEMM_SMALL")) : 0;
+    static const int force_nst = DC_KNOB("DC_GEMM_NST", 0);   // developer knobs
+    static const int force_small = DC_KNOB("DC_GEMM_SMALL", 0);
     if (force_small == 1) return n160 ? launch_gemm<2, 5, 2>(d, st) : launch_gemm<2, 4, 3>(d, st);
     if (force_small == 2) return launch_gemm<2, 2, 3>(d, st);
     if (force_small == 3) return launch_gemm<2, 4, 2>(d, st);
-    static const int hybrid = getenv("DC_GEMM_HYBRID") ? atoi(getenv("DC_GEMM_HYBRID")) : 0;   // measured: no gain over all-DMA
+    static const int hybrid = DC_KNOB("DC_GEMM_HYBRID", 0);   // measured: no gain over all-DMA
     if (hybrid && big >= 256) return n160 ? launch_gemm<4, 5, 2, true>(d, st) : launch_gemm<4, 4, 2, true>(d, st);
     if (hybrid) return n160 ? launch_gemm<2, 5, 2, true>(d, st) : launch_gemm<2, 4, 2, true>(d, st);
     if (force_nst == 4 && big >= 256) return n160 ? launch_gemm<4, 5, 4>(d, st) : launch_gemm<4, 4, 4>(d, st);
@@ -580,7 +580,7 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     // the serial K loop: one LDS-DMA round trip per 64-wide step.  They take a deeper ring — the whole CU's LDS for one
     // workgroup, three or four stages in flight instead of one — with the same tile shape (so the statistics / GroupNorm partial
     // layouts are unchanged).  M = 512, N = 1280, K = 1280: 26 -> see tools/bench_gemm.py 2.
-    static const int deep = getenv("DC_GEMM_DEEP") ? atoi(getenv("DC_GEMM_DEEP")) : 1;        // developer A/B knob
+    static const int deep = DC_KNOB("DC_GEMM_DEEP", 1);        // developer A/B knob
     const long long small = ((M + 63) / 64) * ((d.Cout + bn - 1) / bn) * (d.splitk > 1 ? d.splitk : 1);
     const int KT = (d.C1 + d.C2) >> 6;
     if (deep && small <= 256 && KT >= 6) return n160 ? launch_gemm<2, 5, 4, false, true>(d, st) : launch_gemm<2, 4, 5, false, true>(d, st);

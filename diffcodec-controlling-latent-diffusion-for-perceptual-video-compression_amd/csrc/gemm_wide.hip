@@ -324,8 +324,8 @@ int dc_gemm_wide_gn_chunks(const dc_conv_desc& d)
 // DC_GEMM_WIDE: 0 = never (A/B), 1 = default rule, 2 = whenever legal.
 int dc_gemm_wide_wanted(const dc_conv_desc& d, int epi)
 {
-    static const int mode = getenv("DC_GEMM_WIDE") ? atoi(getenv("DC_GEMM_WIDE")) : 1;
-    static const int min_k = getenv("DC_GEMM_WIDE_MIN_K") ? atoi(getenv("DC_GEMM_WIDE_MIN_K")) : 640;
+    static const int mode = DC_KNOB("DC_GEMM_WIDE", 1);
+    static const int min_k = DC_KNOB("DC_GEMM_WIDE_MIN_K", 640);
     if (mode == 0 || epi < 1 || epi > 5 || d.ksize != 1 || d.gn_ab || d.splitk > 1 || d.out_f32) return 0;
     const int K = d.C1 + d.C2;
     const long long M = (long long)d.N * d.Ho * d.Wo;

@@ -87,7 +87,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("DC_HIP_LIB", LIB_PATH)            # developer knob: A/B a differently compiled build of the same ABI
+    path = LIB_PATH                                          # tools/ assign lib.LIB_PATH to A/B another build of the same ABI
     if not os.path.exists(path):
         raise HipLibraryMissing(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`. "
                                 "There is no CPU fallback on the product path.")

@@ -3,7 +3,6 @@
 Activations are NHWC bf16 tensors of shape [N,H,W,C] (a [B,L,C] token sequence is the same memory with H=1, W=L).
 No arithmetic happens in torch on this path; every function below ends in exactly one or more `lib.call`s."""
 import math
-import os
 
 import torch
 
@@ -20,9 +19,10 @@ def _meta(family, shape, flops, nbytes):
 
 
 
-GN_DIRECT_MAX_PIXELS = int(os.environ.get("DC_GN_DIRECT_MAX_PIXELS", "256"))   # maps up to 16x16: one-launch GroupNorm statistics
-# GroupNorm statistics emitted by the producing conv / GEMM epilogue instead of a read pass (DC_GN_EPILOGUE=0: A/B switch)
-GN_EPILOGUE_STATS = os.environ.get("DC_GN_EPILOGUE", "1") != "0"
+GN_DIRECT_MAX_PIXELS = 256   # maps up to 16x16: one-launch GroupNorm statistics
+# GroupNorm statistics emitted by the producing conv / GEMM epilogue instead of a read pass.  These switches are plain module
+# constants: tools/ assign them for an A/B, nothing on the product path reads the environment.
+GN_EPILOGUE_STATS = True
 
 
 def _stream():
@@ -263,10 +263,10 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
 # GroupNorm+SiLU in front of a conv: folded into the conv's load stage only when the conv has a single output-channel
 # tile (Cout <= 160).  With more N-tiles every workgroup of a pixel tile would redo the same exp/rcp work (Cout/160 x
 # the 1.4x halo overlap); one HBM-bound elementwise pass (which also resolves the skip concat) is cheaper.
-FUSE_GN_MAX_COUT = int(__import__("os").environ.get("DC_FUSE_GN_MAX_COUT", "160"))
+FUSE_GN_MAX_COUT = 160
 # ... except at model batches of at most this many samples (one- and two-frame decodes), where every launch is latency-bound and
 # the separate pass costs a launch of its own: fused everywhere, 175 -> 170 ms per single frame
-FUSE_GN_SMALL_BATCH = int(__import__("os").environ.get("DC_FUSE_GN_SMALL_BATCH", "4"))
+FUSE_GN_SMALL_BATCH = 4
 
 
 def conv_gn_silu(x, pc, ab, x2=None, **kw):
@@ -659,9 +659,10 @@ def pack_sixch(img0_u8, img1_u8):
     return out
 
 
-def blend_tiles_ramp(tiles_nchw, coords, full_hw, feather):
-    """tiles [T,C,th,tw] fp32 in [0,1] on the device, coords [(y1,y2,x1,x2)] full-size windows -> uint8 [H,W,C] (device).
-    Same weights and fp32 op order as tiling.merge_ramp."""
+def blend_tiles_ramp(tiles_nchw, coords, full_hw, feather, scale=255.0):
+    """tiles [T,C,th,tw] fp32 on the device (in [0,1] with scale=255, or already 0..255 pixel values with scale=1: tiles that
+    were quantised to uint8 images first, as the reference's notebook does), coords [(y1,y2,x1,x2)] full-size windows ->
+    uint8 [H,W,C] (device).  Same weights and fp32 op order as tiling.merge_ramp."""
     import numpy as np
     _chk(tiles_nchw, F32, "tiles")
     t, c, th, tw = tiles_nchw.shape
@@ -674,5 +675,5 @@ def blend_tiles_ramp(tiles_nchw, coords, full_hw, feather):
     coords_d = torch.tensor(coords, dtype=torch.int32).reshape(-1, 4).to(dev)
     out = torch.empty((h, w, c), device=dev, dtype=torch.uint8)
     lib.call("dc_blend_tiles_ramp_u8", tiles_nchw.data_ptr(), coords_d.data_ptr(), t, c, th, tw, ramp_d.data_ptr(), f,
-             out.data_ptr(), h, w, 255.0, _stream())
+             out.data_ptr(), h, w, float(scale), _stream())
     return out

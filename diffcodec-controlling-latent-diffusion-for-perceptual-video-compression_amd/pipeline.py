@@ -19,7 +19,8 @@ import torch
 
 from . import ops
 from .controlnet import HipDualFlowControlNet
-from .scheduler import DDIMScheduler
+from . import blocks
+from .scheduler import DDIMScheduler, randn_tensor
 from .unet import HipUNet2DConditionModel
 from .vae import HipAutoencoderKL
 
@@ -160,8 +161,7 @@ class StableDiffusionDualFlowControlNetPipeline:
     def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
         shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if latents is None:
-            gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
-            latents = torch.randn(shape, generator=generator, device=gdev, dtype=torch.float32)
+            latents = randn_tensor(shape, generator, torch.device("cpu") if generator is None else device, torch.float32)
         elif tuple(latents.shape) != shape:
             raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
         return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
@@ -239,8 +239,15 @@ class StableDiffusionDualFlowControlNetPipeline:
             base_scales = [float(controlnet_conditioning_scale)] * len(nets)
         if len(base_scales) != len(nets):
             raise ValueError(f"{len(nets)} ControlNets but {len(base_scales)} conditioning scales")
-        if b_ctrl != batch_size and warp_cond is not None and warp_cond.shape[0] == 1:
-            warp_cond = warp_cond.expand(batch_size, -1, -1, -1).contiguous()
+        if warp_cond is not None:                                              # same checks as the other controls (:187-192)
+            if warp_cond.ndim != 4 or warp_cond.shape[1] != 3:
+                raise ValueError(f"warp_cond must be [B,3,H,W], got {tuple(warp_cond.shape)}")
+            if tuple(warp_cond.shape[-2:]) != (hc, wc):
+                raise ValueError(f"warp_cond is {tuple(warp_cond.shape[-2:])} but the controls are {(hc, wc)}")
+            if warp_cond.shape[0] != batch_size:
+                if warp_cond.shape[0] != 1:
+                    raise ValueError(f"warp_cond batch={warp_cond.shape[0]} vs prompt batch={batch_size} mismatch.")
+                warp_cond = warp_cond.expand(batch_size, -1, -1, -1).contiguous()
         for net in nets:
             if getattr(net, "needs_warp_cond", False) and warp_cond is None:
                 raise ValueError("a ResControlNet is registered: pass warp_cond [B,3,H,W] (flow_resnet.py:58).")
@@ -349,6 +356,11 @@ class StableDiffusionDualFlowControlNetPipeline:
             cn.set_context(st["ctx"])
             cn.prepare_controls(cond, flow, warp)             # hoisted: once per call, at batch B (shared by CFG halves)
         coef, ttab = sched.device_tables(device)
+        if st.get("buf_epoch") != blocks.BUFFER_EPOCH[0]:
+            # a module re-allocated a buffer captured graphs read (FDN gamma/beta, text K/V: another batch size went through
+            # the generic loop, another pipe shares the modules, ...): every graph may hold a freed address
+            self._graphs.clear()
+            st["buf_epoch"] = blocks.BUFFER_EPOCH[0]
         if st.get("tables") != (id(sched), sched.table_version):     # new schedule: graphs captured on the old tables are stale
             self._graphs.clear()
             st["tables"] = (id(sched), sched.table_version)

@@ -11,6 +11,25 @@ import torch
 from . import ops
 
 
+def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
+    """diffusers' `randn_tensor` as the reference reaches it (pipeline.py:269-278 `prepare_latents`, and the variance noise
+    of DDIM's `step(eta > 0)`) [recalled]: the draw happens on the generator's device (a CPU generator draws on the host,
+    the tensor is then moved), in the requested dtype; a LIST of generators draws one batch row per generator."""
+    shape = tuple(int(v) for v in shape)
+    device = torch.device("cpu") if device is None else torch.device(device)
+    if isinstance(generator, (list, tuple)):
+        if len(generator) == 1:
+            generator = generator[0]
+        elif len(generator) != shape[0]:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {shape[0]}. Make sure the batch size matches the length of the generators.")
+        else:
+            rows = [randn_tensor((1,) + shape[1:], g, device, dtype) for g in generator]
+            return torch.cat(rows, 0)
+    gdev = generator.device if isinstance(generator, torch.Generator) else device
+    return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+
+
 class DDIMScheduler:
     order = 1
     init_noise_sigma = 1.0
@@ -95,8 +114,7 @@ class DDIMScheduler:
             a_p = float(self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
             var = (1.0 - a_p) / (1.0 - a_t) * (1.0 - a_t / a_p)
             std = float(eta) * var ** 0.5
-            gdev = generator.device if isinstance(generator, torch.Generator) else dev
-            noise = torch.randn(tuple(model_output.shape), generator=generator, device=gdev, dtype=torch.float32).to(dev)
+            noise = randn_tensor(model_output.shape, generator, dev, model_output.dtype).float()   # drawn in model_output.dtype
             x = sample.float().contiguous()
             eps = model_output.float().contiguous()
             c_x = (a_p / a_t) ** 0.5
