@@ -398,3 +398,12 @@ def unet_config_from_diffusers(cfg_json):
                 cross_attention_dim=cfg_json.get("cross_attention_dim", 768), in_channels=cfg_json.get("in_channels", 4),
                 out_channels=cfg_json.get("out_channels", 4), groups=cfg_json.get("norm_num_groups", 32),
                 down_cross=tuple("CrossAttn" in t for t in dbt), time_cond_proj_dim=cfg_json.get("time_cond_proj_dim"))
+
+
+def vae_config_from_diffusers(cfg_json):
+    """Map a diffusers vae/config.json (AutoencoderKL) onto this package's config dict.  SD-1.5's file predates the
+    `scaling_factor` entry: diffusers' default 0.18215 applies then (pipeline.py:391 divides the latents by it)."""
+    return dict(block_out_channels=tuple(cfg_json["block_out_channels"]), layers_per_block=cfg_json.get("layers_per_block", 2),
+                latent_channels=cfg_json.get("latent_channels", 4), in_channels=cfg_json.get("in_channels", 3),
+                out_channels=cfg_json.get("out_channels", 3), groups=cfg_json.get("norm_num_groups", 32),
+                scaling_factor=cfg_json.get("scaling_factor", 0.18215))

@@ -15,3 +15,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def record():
+    """record(name, value): append a measured value (PSNR, rel-L2 ...) to the file named by $DC_TEST_LOG, so that the bars in
+    the tests can be kept close to what the hardware measures.  Without the variable it does nothing."""
+    path = os.environ.get("DC_TEST_LOG")
+
+    def rec(name, value):
+        if path:
+            with open(path, "a") as fh:
+                fh.write(f"{name}\t{value}\n")
+    return rec

@@ -129,3 +129,27 @@ def test_world2_gloo_tile_sharded_clip_equals_single_rank():
         assert p.exitcode == 0
     assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3, 5]
     assert res[0][2] is True and res[1][3] is True          # frames exist on the gathering rank only
+
+
+def test_driver_edge_cases_empty_share_and_prompt_batch():
+    """a rank with no units keeps the [n,3,th,tw] shape (world > #units), the uint8 gather handles it, and a prompt batch
+    that is neither 1 nor >= the chunk is refused instead of silently truncated."""
+    h = w = 512
+    src = CD.SyntheticSource(h, w, device="cpu")
+    pe = torch.zeros(1, 77, 8)
+    units = CD.plan_units(5, 4, h, w)                                   # 3 units
+    shares = [CD.shard(units, r, 4) for r in range(4)]
+    assert [len(s) for s in shares] == [1, 1, 1, 0]
+    empty = CD.decode_units(FakePipe(), shares[3], src, pe, pe, batch=2)
+    assert empty.shape == (0, 3, 512, 512) and CD.units_to_u8(empty).shape == (0, 512, 512, 3)
+    assert CD.decode_units(FakePipe(), [], src, pe, pe, output="latent").shape == (0, 4, 64, 64)
+    full = torch.cat([CD.decode_units(FakePipe(), s, src, pe, pe, batch=2) for s in shares], 0)      # concatenates without a special case
+    assert full.shape == (3, 3, 512, 512)
+    out = CD.decode_clip(FakePipe(), src, 5, 4, h, w, pe, pe, batch=2, rank=3, world=4, gather=False)
+    assert out["images"].shape == (0, 3, 512, 512) and out["frames"] is None
+    with pytest.raises(ValueError, match="prompt_embeds has batch 2"):
+        CD.decode_units(FakePipe(), units, src, torch.zeros(2, 77, 8), None, batch=3)
+    with pytest.raises(ValueError, match="uint8"):
+        CD.gather_units(full, units, 0, 1)
+    one = CD.gather_units(CD.units_to_u8(full), units, 0, 1)
+    assert one.shape == (3, 512, 512, 3) and one.dtype == torch.uint8

@@ -352,7 +352,7 @@ def test_dual_stream_step_equals_single_stream(small):
         assert torch.equal(x, base)
 
 
-def test_cfg_shared_prefix_equals_duplicated_batch(small):
+def test_cfg_shared_prefix_equals_duplicated_batch(small, record):
     """pipeline.py:313-320 duplicates the latents for classifier-free guidance; the fused loop computes the layers ahead
     of the first text cross-attention once.  Same frame as running the duplicated batch (bf16 rounding is per row, only
     M-dependent split-K order may differ), eager and under hipGraphs, at batch 1 and 2."""
@@ -376,6 +376,7 @@ def test_cfg_shared_prefix_equals_duplicated_batch(small):
         # choices and with them fp32 summation order.  Identical settings are bit-identical (tools/find_nondeterminism.py), so
         # the bar is the reassociation noise of a 3-step decode, not a run-to-run floor
         # (measured 41-48 dB on the reduced-width random-weight model, whose three steps amplify last-bit differences)
+        record(f"cfg_shared_small_b{b}_psnr", T.psnr(a, base))
         assert T.psnr(a, base) > 38.0 and torch.equal(g, a), (b, T.psnr(a, base), T.psnr(g, base))
 
 
@@ -448,7 +449,7 @@ def test_full_size_sd15_vae_decode_and_postprocess():
     assert torch.equal(o8, (want.permute(0, 2, 3, 1) * 255.0).round().to(torch.uint8))
 
 
-def test_full_size_20_step_decode_vs_oracle():
+def test_full_size_20_step_decode_vs_oracle(record):
     """BASELINE configs[1] end to end: one 512x512 frame, 20-step DDIM, CFG 4.5, control scale 1.7, true SD-1.5 widths,
     through the fused loop (hipGraphs, two streams, shared CFG prefix) against the fp32 CPU oracle on identical seeded
     weights and inputs.  Measured 47.8 dB / latent rel-L2 0.011 (tools/full_decode_parity.py); the oracle takes ~40 s."""
@@ -480,8 +481,10 @@ def test_full_size_20_step_decode_vs_oracle():
     ref_img, ref_lat = R.decode_frame(usd, csd, vsd, W.SD15_UNET_CONFIG, W.SD15_VAE_CONFIG, cond, flow, pe, npe, lat,
                                       return_latents=True, **kw)
     assert img.shape == ref_img.shape == (1, 3, 512, 512)
-    assert T.rel_l2(lat_d, ref_lat) < 4e-2
-    assert T.psnr(img, ref_img) > 35.0
+    record("c2_full_20step_psnr", T.psnr(img, ref_img))
+    record("c2_full_20step_latent_rel_l2", T.rel_l2(lat_d, ref_lat))
+    assert T.rel_l2(lat_d, ref_lat) < 2e-2           # measured 0.011; the decode is bit-reproducible, so the bars sit close
+    assert T.psnr(img, ref_img) > 45.0               # measured 47.6-47.8 dB
 
 
 # ------------------------------------------------------------------------------------------- config 4 / clip driver
@@ -585,7 +588,7 @@ def test_clip_driver_gop12_and_tiled_frame(small):
     assert (corner - tiles[0, :, :128, :128]).abs().max().item() <= 0.5 / 255 + 1e-6
 
 
-def test_config4_full_size_960x512_gop4_vs_oracle():
+def test_config4_full_size_960x512_gop4_vs_oracle(record):
     """BASELINE config 4 end to end at true SD-1.5 widths: 960x512 frames as two 512x512 windows (x = 0 and 448), GOP-4 (3 inter
     frames -> 6 units), DualFlowControlNet + ResControlNet with warp_cond, through the clip driver; every unit against the
     oracle's fp32 loop with both nets, and the blended frames against the host blend of the oracle's tiles.  2 DDIM steps keep
@@ -623,7 +626,8 @@ def test_config4_full_size_960x512_gop4_vs_oracle():
                              res_conditioning_scale=1.0, **kw)
         ref_tiles.append(ref[0])
         p = T.psnr(imgs[k:k + 1], ref)
-        assert p > 32.0, (k, p)
+        record(f"c4_full_unit{k}_psnr", p)
+        assert p > 37.0, (k, p)                         # tightened in round 3 (deterministic decode): within ~3 dB of the measured values
     for fi, f in enumerate((1, 2, 3)):
         host = [np.asarray(t.permute(1, 2, 0).numpy() * 255.0, np.float32) for t in ref_tiles[2 * fi:2 * fi + 2]]
         want = tiling.merge_ramp(host, [u.window for u in units[2 * fi:2 * fi + 2]], (h, w), order="hwc", feather=64)

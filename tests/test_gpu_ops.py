@@ -604,3 +604,63 @@ def test_blend_tiles_ramp_equals_host_merge(ops, hw, tile, overlap):
     dev = ops.blend_tiles_ramp(tiles.to(DEV), coords, (h, w), overlap).cpu().numpy()
     assert dev.shape == host.shape == (h, w, 3) and dev.dtype == np.uint8
     assert np.array_equal(dev, host)
+
+
+# ------------------------------------------------------------------------------------------- single-pass variance under outliers
+@pytest.mark.parametrize("ratio", [30.0, 100.0])
+@pytest.mark.parametrize("k", [1, 3])
+def test_group_norm_epilogue_partials_with_outlier_channel_means(ops, ratio, k):
+    """the GroupNorm partials of a conv / GEMM epilogue are (sum, sum of squares) in fp32 and the finalize forms
+    E[x^2] - mean^2.  Trained SD-1.5 activations have channels whose |mean| is tens of sigma; here every group of the OUTPUT
+    sits at |mean| / sigma = 30 and 100 (a large per-group bias on a unit-variance conv output).  Bar: the per-(sample, channel)
+    scale / shift against a two-pass float64 reference over the SAME stored bf16 tensor: rstd within 2 % (the bf16 grid of the
+    tensor itself is 0.4 % of the mean, i.e. up to 0.4 sigma at ratio 100)."""
+    g = torch.Generator().manual_seed(97)
+    n, h, w, cin, cout, groups = 2, 32, 32, 64, 320, 32
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV, torch.bfloat16)
+    wgt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)          # unit-variance outputs
+    sign = torch.where(torch.arange(groups) % 2 == 0, 1.0, -1.0).repeat_interleave(cout // groups)
+    bias = sign * ratio * (1.0 + 0.05 * torch.randn(groups, generator=g)).repeat_interleave(cout // groups)
+    y = ops.conv(x, ops.PackedConv(wgt, bias, DEV), gn_part=True)
+    assert hasattr(y, "gn_part")
+    gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)
+    for name, ab in (("epilogue partials", ops.group_norm_ab(y, gamma, beta, groups, 1e-5)),
+                     ("read pass", ops.group_norm_ab(y.clone(), gamma, beta, groups, 1e-5))):
+        yd = y.double().reshape(n, h * w, groups, cout // groups)
+        mean = yd.mean(dim=(1, 3))
+        var = ((yd - mean[:, None, :, None]) ** 2).mean(dim=(1, 3))
+        assert 0.7 * ratio < (mean.abs() / var.sqrt()).min().item()                  # the case really is what it says
+        rstd = (var + 1e-5).rsqrt().repeat_interleave(cout // groups, 1)
+        a_ref = rstd * gamma.double()[None]
+        b_ref = beta.double()[None] - mean.repeat_interleave(cout // groups, 1) * a_ref
+        a, b = ab[..., 0].double(), ab[..., 1].double()
+        rel = ((a - a_ref).abs() / a_ref.abs()).max().item()
+        assert rel < 2e-2, (name, ratio, k, rel)
+        # the normalised value of a typical element: (x * a + b) has O(1) magnitude, so the shift must be right to ~1e-2 absolute
+        xs = mean.repeat_interleave(cout // groups, 1)
+        assert ((xs * a + b) - (xs * a_ref + b_ref)).abs().max().item() < 3e-2, (name, ratio, k)
+
+
+@pytest.mark.parametrize("ratio", [30.0, 100.0])
+def test_layer_norm_fold_with_outlier_row_means(ops, ratio):
+    """The LayerNorm fold Linear(LN(x)) = rstd * (x W'^T - mean * colsum(W')) + b' at |row mean| / sigma = 30 and 100, statistics
+    from the producing GEMM's epilogue: against F.linear(F.layer_norm(.)) in float64 on the SAME stored bf16 rows.  The
+    subtraction cancels `ratio` times the result's magnitude in fp32 accumulators — two decimal digits of seven."""
+    g = torch.Generator().manual_seed(5)
+    c, m = 320, 256
+    a_in = bf(torch.randn(1, m, c, generator=g))
+    wo = bf(torch.randn(c, c, generator=g) / math.sqrt(c))
+    bo = torch.full((c,), ratio)                                          # rows: unit sigma around `ratio`
+    st = torch.empty((m, ops.row_stats_parts(c), 2), device=DEV)
+    t = ops.linear(a_in.to(DEV, torch.bfloat16), ops.PackedConv(wo, bo, DEV), stats_out=st)
+    td = t.double().cpu()[0]
+    mean, var = td.mean(-1), td.var(-1, unbiased=False)
+    assert (mean.abs() / var.sqrt()).min().item() > 0.7 * ratio
+    gamma, beta = 1 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    wq = bf(torch.randn(3 * c, c, generator=g) / math.sqrt(c))
+    ref = F.linear(F.layer_norm(td, (c,), gamma.double(), beta.double(), 1e-5), wq.double())
+    mr = ops.ln_finalize(st, c, 1e-5).double().cpu()
+    assert ((mr[:, 1] - (var + 1e-5).rsqrt()).abs() / (var + 1e-5).rsqrt()).max().item() < 2e-2
+    out = ops.linear(t, ops.PackedConv(wq, None, DEV, ln=(gamma, beta, 1e-5)), ln_stats=ops.ln_finalize(st, c, 1e-5))
+    err = (out.double().cpu()[0] - ref).abs()
+    assert err.mean().item() < 2e-2 and err.max().item() < 0.15, (ratio, err.mean().item(), err.max().item())

@@ -153,3 +153,36 @@ def test_ddim_eta_matches_oracle_on_cpu_tensors():
         std = 0.7 * ((1 - a_p) / (1 - a_t) * (1 - a_t / a_p)) ** 0.5
         mine = (a_p / a_t) ** 0.5 * x + (-(a_p * (1 - a_t) / a_t) ** 0.5 + (1 - a_p - std * std) ** 0.5) * e + std * nz
         torch.testing.assert_close(mine, r.step(e, t, x, 0.7, nz), rtol=1e-5, atol=1e-5)
+
+
+def test_warp_cond_is_validated_like_the_other_controls():
+    """warp_cond [B,3,H,W] (flow_resnet.py:58) gets the checks pipeline.py:187-192,249 apply to the other controls."""
+    from types import SimpleNamespace
+    from diffcodec_amd.pipeline import StableDiffusionDualFlowControlNetPipeline as P
+    vae = SimpleNamespace(config=SimpleNamespace(block_out_channels=[1, 2, 3, 4], scaling_factor=0.18215))
+    unet = SimpleNamespace(config=SimpleNamespace(in_channels=4, time_cond_proj_dim=None), device=torch.device("cpu"))
+    pipe = P(vae, None, None, unet, None, DDIMScheduler(), None, None)
+    pe = torch.zeros(2, 77, 768)
+    ok = dict(prompt_embeds=pe, negative_prompt_embeds=pe, controlnet_cond=torch.zeros(2, 6, 64, 64), flow_cond=torch.zeros(2, 4, 64, 64))
+    with pytest.raises(ValueError, match=r"warp_cond must be \[B,3,H,W\]"):
+        pipe(**ok, warp_cond=torch.zeros(2, 4, 64, 64))
+    with pytest.raises(ValueError, match="warp_cond is"):
+        pipe(**ok, warp_cond=torch.zeros(2, 3, 32, 64))
+    with pytest.raises(ValueError, match="warp_cond batch=3"):
+        pipe(**ok, warp_cond=torch.zeros(3, 3, 64, 64))
+
+
+def test_randn_tensor_follows_diffusers_generator_rules():
+    """prepare_latents / DDIM variance noise (pipeline.py:269-278, :289): CPU generator -> host draw; a list of generators draws
+    one batch row each; a list of the wrong length is the library's ValueError."""
+    from diffcodec_amd.scheduler import randn_tensor
+    a = randn_tensor((2, 4, 8, 8), torch.Generator().manual_seed(3), "cpu")
+    assert torch.equal(a, torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(3)))
+    gens = [torch.Generator().manual_seed(k) for k in (5, 6)]
+    b = randn_tensor((2, 4, 8, 8), gens, "cpu")
+    want = torch.cat([torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(k)) for k in (5, 6)], 0)
+    assert torch.equal(b, want)
+    assert torch.equal(randn_tensor((2, 4, 8, 8), [torch.Generator().manual_seed(3)], "cpu"), a)      # a one-element list is that generator
+    with pytest.raises(ValueError, match="list of generators of length 3"):
+        randn_tensor((2, 4, 8, 8), gens + gens[:1], "cpu")
+    assert randn_tensor((1, 4, 8, 8), None, "cpu", torch.bfloat16).dtype == torch.bfloat16
