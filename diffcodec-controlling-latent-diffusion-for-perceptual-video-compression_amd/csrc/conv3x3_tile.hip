@@ -563,11 +563,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], e_act);
             }
-            v *= d.out_scale;
-            if (e_res) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
-            }
+            if (e_res) v = dc_scale_res(v, d.out_scale, rr[tm][tn]);
+            else v *= d.out_scale;
             if (want_gn) {
                 gs[tn] += v;
                 gq[tn] += v * v;

@@ -42,15 +42,16 @@ __device__ __forceinline__ float dc_act(float x, int act) { return x * __builtin
 // instead of libm erff's branchy polynomial (~3x the VALU work in the GEGLU epilogue).
 __device__ __forceinline__ float dc_erf_fast(float x)
 {
+#pragma clang fp contract(off)
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
     float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
+    p = __builtin_fmaf(p, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float r = 1.0f - p * t * e;
+    const float r = __builtin_fmaf(-(p * t), e, 1.0f);
     return copysignf(r, x);
 }
 #ifndef DC_GELU_VARIANT
@@ -58,11 +59,37 @@ __device__ __forceinline__ float dc_erf_fast(float x)
 #endif                          // GELU could buy), never built into the product library
 __device__ __forceinline__ float dc_gelu_erf(float x)
 {
+#pragma clang fp contract(off)
 #if DC_GELU_VARIANT == 1
     return x;
 #else
     return 0.5f * x * (1.0f + dc_erf_fast(x * 0.70710678118654752440f));
 #endif
+}
+
+// Epilogue arithmetic shared by the GEMM / conv kernels, with the fused multiply-adds WRITTEN OUT.  Left to -ffp-contract, hipcc
+// fuses `v * scale + residual` (and the LayerNorm fold's `v - mean * colsum`) in some instantiations / unrolled copies of the same
+// source expression and not in others (first build of gemm_rowpanel.hip: 109 of 21 M outputs one bf16 ulp away from gemm_dma.hip
+// with out_scale = 0.75, all in the second row tile) — so the same row could round differently depending on which kernel, or
+// which copy of a loop body, produced it.  One definition, one rounding sequence, every kernel: contraction is switched off inside
+// these helpers (hipcc's default -ffp-contract=fast-honor-pragmas fuses only operations that BOTH carry the contract flag, so a
+// multiply in here cannot be fused with an add at the call site either).
+__device__ __forceinline__ f32x4 dc_scale_res(f32x4 v, float scale, bf16x4 rr)
+{
+#pragma clang fp contract(off)
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(v[r], scale, (float)rr[r]);
+    return o;
+}
+// Linear(LN(x)) = rstd * (x W'^T - mean * colsum(W')) (+ b'): the per-row half of the folded LayerNorm
+__device__ __forceinline__ f32x4 dc_ln_fold(f32x4 v, float mean, float rstd, f32x4 cs)
+{
+#pragma clang fp contract(off)
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __builtin_fmaf(-mean, cs[r], v[r]) * rstd;
+    return o;
 }
 
 __device__ __forceinline__ float dc_wave_sum(float v)
@@ -152,3 +179,11 @@ static inline void dc_set_max_dyn_lds(const void* kern, int bytes, std::atomic<u
     done.fetch_or(bit, std::memory_order_release);
 }
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+// Partials per output row of a `stats_out` launch (the value dc_gemm_row_stats_parts reports to the host): one per wave column
+// slice of the tile grid of the 128-row kernel; kernels that produce fewer (gemm_rowpanel.hip: one) zero-fill the rest.
+__host__ __device__ static inline int dc_row_stats_parts_rule(int Cout)
+{
+    if (Cout <= 0) return 0;
+    const int bn = (Cout % 160 == 0) ? 160 : 128;       // the N tile dc_gemm_dma_launch picks for a plain (non-GEGLU) epilogue
+    return 2 * ((Cout + bn - 1) / bn);                  // two wave column slices per N tile
+}

@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                 for (int tp = 0; tp < TN / 2; ++tp) {
                     f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
                     if (e_ln) {
-                        h = (h - ln_mr[tm][0] * cs[2 * tp]) * ln_mr[tm][1];
-                        g = (g - ln_mr[tm][0] * cs[2 * tp + 1]) * ln_mr[tm][1];
+                        h = dc_ln_fold(h, ln_mr[tm][0], ln_mr[tm][1], cs[2 * tp]);
+                        g = dc_ln_fold(g, ln_mr[tm][0], ln_mr[tm][1], cs[2 * tp + 1]);
                     }
                     h += bv[2 * tp];
                     g += bv[2 * tp + 1];
@@ -359,18 +359,15 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
                     const int nl = (wn * TN + tn) * 16 + 4 * fq;
                     const int nb = n0 + nl;
                     f32x4 v = acc[tn][tm];
-                    if (e_ln) v = (v - ln_mr[tm][0] * cs[tn]) * ln_mr[tm][1];
+                    if (e_ln) v = dc_ln_fold(v, ln_mr[tm][0], ln_mr[tm][1], cs[tn]);
                     v += bv[tn];
                     if (e_rowadd && nb < d.Cout) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
                     if (e_act) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], e_act);
                     }
-                    v *= d.out_scale;
-                    if (e_res) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
-                    }
+                    if (e_res) v = dc_scale_res(v, d.out_scale, rr[tm][tn]);
+                    else v *= d.out_scale;
                     bf16x4 pk;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
@@ -468,12 +465,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const dc_conv_desc d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
             }
-            v *= d.out_scale;
-            if (d.residual) {
-                const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
+            if (d.residual) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + off));
+            else v *= d.out_scale;
             if (d.out_f32) {
                 *(f32x4*)((float*)d.out + off) = v;
             } else {
@@ -530,12 +523,7 @@ int launch_gemm(const dc_conv_desc& d, hipStream_t st)
 
 }  // namespace
 
-extern "C" int dc_gemm_row_stats_parts(int Cout)
-{
-    if (Cout <= 0) return 0;
-    const int bn = (Cout % 160 == 0) ? 160 : 128;       // the N tile dc_gemm_dma_launch picks for a plain (non-GEGLU) epilogue
-    return 2 * ((Cout + bn - 1) / bn);                  // one partial per wave column slice (two per N tile)
-}
+extern "C" int dc_gemm_row_stats_parts(int Cout) { return dc_row_stats_parts_rule(Cout); }
 
 int dc_gemm_dma_supported(const dc_conv_desc& d)
 {
@@ -547,6 +535,10 @@ int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);
 int dc_gemm_wide_wanted(const dc_conv_desc& d, int epi);
 int dc_gemm_wide_launch(const dc_conv_desc& d, int epi, hipStream_t st);
 int dc_gemm_wide_gn_chunks(const dc_conv_desc& d);
+// gemm_rowpanel.hip: the K = 320 kernel that keeps a 256-row activation panel in registers and streams only W
+int dc_gemm_rowpanel_wanted(const dc_conv_desc& d, int epi);
+int dc_gemm_rowpanel_launch(const dc_conv_desc& d, int epi, hipStream_t st);
+int dc_gemm_rowpanel_gn_chunks(const dc_conv_desc& d);
 
 int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
 {
@@ -556,6 +548,7 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     if (d.gn_part_out && dc_gemm_dma_gn_chunks(d) == 0) return DC_ERR_INVALID;
     {
         const int epi = epi_mode(d);
+        if (dc_gemm_rowpanel_wanted(d, epi)) return dc_gemm_rowpanel_launch(d, epi, st);
         if (dc_gemm_wide_wanted(d, epi)) return dc_gemm_wide_launch(d, epi, st);
     }
     if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;
@@ -594,6 +587,7 @@ int dc_gemm_dma_gn_chunks(const dc_conv_desc& d)
     {   // the launch decision must be the one dc_gemm_dma_launch takes with gn_part_out set (the host sizes the buffer from here)
         dc_conv_desc q = d;
         if (!q.gn_part_out) q.gn_part_out = (float*)(uintptr_t)16;
+        if (dc_gemm_rowpanel_wanted(q, epi_mode(q))) return dc_gemm_rowpanel_gn_chunks(q);
         if (dc_gemm_wide_wanted(q, epi_mode(q))) return dc_gemm_wide_gn_chunks(q);
     }
     const long long M = (long long)d.N * d.Ho * d.Wo;

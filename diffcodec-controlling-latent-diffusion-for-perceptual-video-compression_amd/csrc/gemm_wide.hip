@@ -226,8 +226,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
             for (int tp = 0; tp < TN / 2; ++tp) {
                 f32x4 h = acc[2 * tp][tm], g = acc[2 * tp + 1][tm];
                 if (e_ln) {
-                    h = (h - ln_mr[tm][0] * cs[2 * tp]) * ln_mr[tm][1];
-                    g = (g - ln_mr[tm][0] * cs[2 * tp + 1]) * ln_mr[tm][1];
+                    h = dc_ln_fold(h, ln_mr[tm][0], ln_mr[tm][1], cs[2 * tp]);
+                    g = dc_ln_fold(g, ln_mr[tm][0], ln_mr[tm][1], cs[2 * tp + 1]);
                 }
                 h += bv[2 * tp];
                 g += bv[2 * tp + 1];
@@ -244,13 +244,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
                 const int nl = (wn * TN + tn) * 16 + 4 * fq;
                 const int nb = n0 + nl;
                 f32x4 v = acc[tn][tm];
-                if (e_ln) v = (v - ln_mr[tm][0] * cs[tn]) * ln_mr[tm][1];
+                if (e_ln) v = dc_ln_fold(v, ln_mr[tm][0], ln_mr[tm][1], cs[tn]);
                 v += bv[tn];
-                v *= d.out_scale;
-                if (e_res) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[tm][tn][r];
-                }
+                if (e_res) v = dc_scale_res(v, d.out_scale, rr[tm][tn]);
+                else v *= d.out_scale;
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];

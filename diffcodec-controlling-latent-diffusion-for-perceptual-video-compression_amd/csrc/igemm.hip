@@ -282,12 +282,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const dc_conv_desc d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
             }
-            v *= d.out_scale;
-            if (d.residual) {
-                const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-            }
+            if (d.residual) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + off));
+            else v *= d.out_scale;
             if (d.out_f32) {
                 *(f32x4*)((float*)d.out + off) = v;
             } else {
@@ -317,12 +313,8 @@ __global__ void splitk_finish_kernel(const dc_conv_desc d, long long total4)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
     }
-    v *= d.out_scale;
-    if (d.residual) {
-        const bf16x4 rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-    }
+    if (d.residual) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + off));
+    else v *= d.out_scale;
     if (d.out_f32) {
         *(f32x4*)((float*)d.out + off) = v;
     } else {

@@ -110,7 +110,9 @@ def test_c5_full_size_1080p_frame_15_windows_50_steps(full):
     assert fr.shape == (H, Wd, 3) and fr.dtype == np.uint8 and 20 < fr.mean() < 235
     u8 = CD.units_to_u8(imgs).cpu().numpy()
     assert np.array_equal(fr[:448, :448], u8[0][:448, :448])                  # covered by window 0 only: verbatim
-    assert np.array_equal(fr[632:, 1472:], u8[14][64:, 64:])                  # bottom-right corner: last window only
+    # bottom-right corner: the border windows are shifted inward, so the last window (rows 568.., columns 1408..) is alone only
+    # beyond its neighbours' ends (rows >= 448 + 512, columns >= 1344 + 512)
+    assert np.array_equal(fr[960:, 1856:], u8[14][960 - 568:, 1856 - 1408:])
     # overlap of windows 0 and 1 (x in [448, 512), y < 448): a convex blend of the two tiles, rounded
     a, b, m = u8[0][:448, 448:512].astype(np.int32), u8[1][:448, 0:64].astype(np.int32), fr[:448, 448:512].astype(np.int32)
     assert ((m >= np.minimum(a, b) - 1) & (m <= np.maximum(a, b) + 1)).all()

@@ -3,11 +3,14 @@ plain, residual, GEGLU and folded-LayerNorm epilogues.  20 launches replayed fro
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffcodec_amd import ops
+from diffcodec_amd import lib, ops
+if os.environ.get("DC_LIB_PATH"):        # A/B another build of the same ABI (tools/build_dev.sh)
+    lib.LIB_PATH = os.path.abspath(os.environ["DC_LIB_PATH"])
 
 DEV = "cuda"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 # (rows per sample, cin, cout, kind)  kind: p plain, r residual(+stats), g geglu, l ln-folded, lg ln-folded geglu
+ONLY_K = int(os.environ.get("DC_BENCH_K", "0"))
 SHAPES = [(4096, 320, 320, "p"), (4096, 320, 320, "r"), (4096, 320, 960, "l"), (4096, 320, 2560, "lg"), (4096, 1280, 320, "r"),
           (1024, 640, 640, "r"), (1024, 640, 1920, "l"), (1024, 640, 5120, "lg"), (1024, 2560, 640, "r"),
           (256, 1280, 1280, "r"), (256, 1280, 3840, "l"), (256, 1280, 10240, "lg"), (256, 5120, 1280, "r"),
@@ -15,6 +18,8 @@ SHAPES = [(4096, 320, 320, "p"), (4096, 320, 320, "r"), (4096, 320, 960, "l"), (
 g = torch.Generator().manual_seed(0)
 print("us  TFLOP/s  GB/s  shape")
 for (hw, cin, cout, kind) in SHAPES:
+    if ONLY_K and cin != ONLY_K:
+        continue
     m = B * hw
     x = torch.randn(1, m, cin, generator=g).to(DEV, torch.bfloat16)
     w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
