@@ -11,7 +11,8 @@ checkpoint is reachable offline), bf16 compute with fp32 accumulation.
   --config c2 (default)  BASELINE configs[1]: 512x512 frames, one DualFlowControlNet (the configuration `metric` is quoted on)
   --config c4            BASELINE configs[3]: 960x512 frames = two 512x512 windows each, GOP-4, DualFlowControlNet +
                          ResControlNet (warp_cond); frames/s counts whole 960x512 frames
-  --config validation    what validation.py:37,106,132-146 runs: UniPC multistep, 40 steps, FreeU, CFG; not the headline either
+  (the line also carries `validation_config`: what validation.py:37,106,132-146 runs — UniPC multistep, 40 steps, FreeU, CFG,
+   a string prompt through the text tower — timed after the headline region)
 N > 1: one process per GPU (torch.distributed / RCCL); units are sharded across ranks with no data-path collective; rank 0
 synthesises the weights and broadcasts the packed tensors once (outside the timed region).  Prints ONE JSON line on rank 0.
 `python bench.py --gpus N` with no launcher around it starts its own N ranks (child processes, before this process makes any
@@ -361,6 +362,65 @@ def main():
                        tflops=round(1.1167 * x.shape[0] / (ms * 1e-3), 1),
                        note="AutoencoderKL.encode 512x512 -> 64x64 moments, 1116.7 GFLOP of reference work per frame")
 
+    # ---- the configuration validation.py:37,106,132-146 actually runs (UniPC multistep, 40 steps, FreeU, CFG, a string prompt
+    #      through the text tower), after the timed region and never the headline: same clip driver, same units, the fused /
+    #      graphed loop with dc_cfg_unipc_step as its scheduler kernel.  The text tower is HipCLIPTextModel with random-init
+    #      weights; the tokenizer's vocabulary files are not reachable offline, so a stand-in maps the words to ids.
+    validation = None
+    if extras and not c4:
+        from diffcodec_amd import weights as W
+        from diffcodec_amd.scheduler import UniPCMultistepScheduler
+        from diffcodec_amd.text_encoder import HipCLIPTextModel
+
+        class WordHashTokenizer:
+            """stand-in for CLIPTokenizer (BOS, one id per word, EOS, EOS padding to 77): the bench needs ids, not English"""
+            model_max_length = 77
+
+            def __call__(self, texts, **kw):
+                rows = []
+                for t in texts:
+                    ids = [49406] + [1 + (hash_word(w) % 49000) for w in t.split()][:75] + [49407]
+                    rows.append(ids + [49407] * (77 - len(ids)))
+                return type("Tok", (), {"input_ids": torch.tensor(rows, dtype=torch.int64)})()
+
+        def hash_word(w):
+            h = 2166136261
+            for ch in w.encode():
+                h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+            return h
+
+        t0 = time.perf_counter()
+        clip = HipCLIPTextModel(W.synthesize(W.clip_text_spec(), seed=7), None, device)
+        ddim = pipe.scheduler
+        pipe.text_encoder, pipe.tokenizer = clip, WordHashTokenizer()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        vpe, vnpe = pipe.encode_prompt("a city street at dusk, high quality", device, 1, True, negative_prompt="blurry, low quality")
+        torch.cuda.synchronize()
+        text_ms = (time.perf_counter() - t1) * 1e3
+        pipe.scheduler = UniPCMultistepScheduler()
+        pipe.enable_freeu(s1=0.9, s2=0.2, b1=1.2, b2=1.4)
+        vkw = dict(kw, num_inference_steps=40, guidance_scale=7.5)
+        try:
+            vstep = lambda i: CD.decode_units(pipe, mine, sources[i % 2], vpe, vnpe, batch=len(mine), frame_size=(height, width), **vkw)
+            vstep(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            vout = vstep(1)
+            torch.cuda.synchronize()
+            vms = (time.perf_counter() - t1) * 1e3
+            assert torch.isfinite(vout).all()
+        finally:
+            pipe.disable_freeu()
+            pipe.scheduler = ddim
+            pipe.text_encoder = pipe.tokenizer = None
+        validation = dict(scheduler="UniPCMultistepScheduler (bh2, order 2)", steps=40, freeu=dict(s1=0.9, s2=0.2, b1=1.2, b2=1.4),
+                          guidance_scale=7.5, frames_per_step=F, ms_per_step=round(vms, 2), frames_per_s=round(F * 1e3 / vms, 3),
+                          text_encode_ms=round(text_ms, 2), fused_loop=True, hip_graphs=not args.no_graphs,
+                          note="validation.py:37,106,132-146: UniPC + FreeU + CFG 7.5 + string prompt (stand-in tokenizer, random-init "
+                               "CLIP tower); 40 denoising steps per frame, so 2x the headline's model work per frame")
+        del clip, vout
+
     # ---- roofline leg (after the timed region): ONE eager step with every C-ABI launch bracketed by two HIP events on the
     #      launch stream (lib.LaunchTimer): each kernel's own duration inside the real step — real operands, real cache
     #      state, host launch gaps excluded.  Agrees with the rocprofv3 --kernel-trace --stats CSV under profiles/.
@@ -434,7 +494,7 @@ def main():
             "frame_tflop_algorithmic": None if c4 else round(TFLOP_PER_FRAME, 2),
             "frame_mfma_frac": None if c4 else round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
             "single_frame": single, "gop12_batch": gop12, "c3_clip_strong": c3, "gather_ms": gather_ms,
-            "unet_forward": unet_fwd, "vae_encode": vae_enc,
+            "unet_forward": unet_fwd, "vae_encode": vae_enc, "validation_config": validation,
             "roofline": roof, "kernel_families": families, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

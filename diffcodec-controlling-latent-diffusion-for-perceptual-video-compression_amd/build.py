@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffcodec_hip.so")
-SOURCES = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip", "gemm_rowpanel.hip", "attention.hip", "norm.hip", "splat.hip", "conv_direct.hip", "elementwise.hip", "text.hip"]
+SOURCES = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip", "gemm_rowpanel.hip", "attention.hip", "norm.hip", "splat.hip", "conv_direct.hip", "conv_f32_mfma.hip", "elementwise.hip", "text.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

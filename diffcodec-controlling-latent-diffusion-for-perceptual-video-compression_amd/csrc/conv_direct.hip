@@ -332,12 +332,19 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const bf16_t* __re
 
 }  // namespace
 
+// conv_f32_mfma.hip
+int dc_conv_f32_mfma_wanted(int Cin, int H, int W, int Cout, int stride);
+int dc_conv_f32_mfma_launch(const float* x, long long xbs, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+                            int Cout, int stride, int silu, hipStream_t st);
+
 extern "C" int dc_conv3x3_nchw_f32(const float* x, long long x_batch_stride, const float* w, const float* bias, float* y,
                                    int N, int Cin, int H, int W, int Cout, int stride, int silu, void* stream)
 {
     if (!x || !w || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2 && stride != 4)) return DC_ERR_INVALID;
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
+    // GEMM-shaped layers (>= 16 input channels, output channels in whole 32-wide tiles): exact-fp32 MFMA form, conv_f32_mfma.hip
+    if (dc_conv_f32_mfma_wanted(Cin, H, W, Cout, stride)) return dc_conv_f32_mfma_launch(x, x_batch_stride, w, bias, y, N, Cin, H, W, Cout, stride, silu, st);
     // the register-blocked form (16 x 16 pixels x 64 output channels per workgroup) wins where there are >= 64 output channels to
     // share an input patch and the map is at least 64 wide (or 32 wide with >= 160 channels); measured per shape, tools/bench_f32conv.py
     static const int blk = DC_KNOB("DC_F32CONV_BLOCKED", 1);     // developer A/B knob

@@ -170,15 +170,62 @@ __global__ void freeu_backbone_kernel(const bf16_t* __restrict__ x, bf16_t* __re
 }
 // y = a*x0 + b*x1 + c*x2 + d*x3 (fp32; null pointers skipped) — scheduler state updates (UniPC predictor / corrector,
 // epsilon -> x0 conversion, CFG combine in the generic loop: pipeline.py:370-375)
+// y = a x0 + b x1 + c x2 + d x3, terms with `has` false skipped: ONE definition of the rounding sequence (products folded into the
+// running sum by explicit fused multiply-adds, in term order) shared by dc_lincomb4_f32 — the generic scheduler path — and the
+// fused UniPC step below, so the two paths are bit-identical by construction.
+__device__ __forceinline__ float lincomb4(float a, float x0, float b, float x1, bool h1, float c, float x2, bool h2, float d, float x3,
+                                          bool h3)
+{
+#pragma clang fp contract(off)
+    float v = a * x0;
+    if (h1) v = __builtin_fmaf(b, x1, v);
+    if (h2) v = __builtin_fmaf(c, x2, v);
+    if (h3) v = __builtin_fmaf(d, x3, v);
+    return v;
+}
 __global__ void lincomb4_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ x2,
                                 const float* __restrict__ x3, float a, float b, float c, float d, float* __restrict__ y, long long n)
 {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float v = a * x0[i];
-        if (x1) v += b * x1[i];
-        if (x2) v += c * x2[i];
-        if (x3) v += d * x3[i];
-        y[i] = v;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = lincomb4(a, x0[i], b, x1 ? x1[i] : 0.f, x1 != nullptr, c, x2 ? x2[i] : 0.f, x2 != nullptr, d, x3 ? x3[i] : 0.f,
+                        x3 != nullptr);
+}
+// CFG combine + one UniPCMultistepScheduler.step (bh2, predict_x0, order <= 2: validation.py:37) as ONE pass over the latent-sized
+// state, every coefficient read from a device table row indexed by the device step counter — so a captured denoising step
+// replays for all steps, the order warm-up and the lower-order final step included (they are data: flags in the row).
+// Row (DC_UNIPC_ROW floats): 0 1/alpha_i  1 -sigma_i/alpha_i | 2 flags (1 corrector, 2 corrector uses m1, 4 predictor uses m1)
+//   3..6 corrector coefficients of (last_sample, m0, m_t, m1) | 7..9 predictor coefficients of (x, m_t, m1)
+// State (fp32, NCHW like the latents): m0 / m1 = the two most recent x0-predictions, last = the sample the previous predictor
+// started from.  The arithmetic is scheduler.py's sequence of dc_lincomb4_f32 launches, term for term.
+#define DC_UNIPC_ROW 12
+__global__ void cfg_unipc_kernel(const float* __restrict__ eps, float* __restrict__ lat, float* __restrict__ m0, float* __restrict__ m1,
+                                 float* __restrict__ last, bf16_t* __restrict__ model_in, const float* __restrict__ coef,
+                                 const int* __restrict__ step, float guidance, int cfg, int B, int C, long long HW)
+{
+    const long long total = (long long)B * C * HW;
+    const float* r = coef + (long long)(*step) * DC_UNIPC_ROW;
+    const float ca = r[0], ce = r[1];
+    const int flags = (int)r[2];
+    const bool corr = flags & 1, corr_m1 = flags & 2, pred_m1 = flags & 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW;
+        const int c = (int)((i / HW) % C);
+        const long long b = i / (HW * C);
+        float e;
+        if (cfg) e = lincomb4(1.0f - guidance, eps[(b * HW + p) * C + c], guidance, eps[((b + B) * HW + p) * C + c], true, 0.f, 0.f, false, 0.f, 0.f, false);
+        else e = eps[(b * HW + p) * C + c];
+        float x = lat[i];
+        const float mt = lincomb4(ca, x, ce, e, true, 0.f, 0.f, false, 0.f, 0.f, false);              // convert_model_output
+        const float pm0 = m0[i], pm1 = m1[i];
+        if (corr) x = lincomb4(r[3], last[i], r[4], pm0, true, r[5], mt, true, r[6], pm1, corr_m1);     // multistep_uni_c_bh_update
+        last[i] = x;
+        m1[i] = pm0;
+        m0[i] = mt;
+        const float xn = lincomb4(r[7], x, r[8], mt, true, r[9], pm0, pred_m1, 0.f, 0.f, false);        // multistep_uni_p_bh_update
+        lat[i] = xn;
+        const bf16_t xb = (bf16_t)xn;
+        model_in[(b * HW + p) * C + c] = xb;
+        if (cfg) model_in[((b + B) * HW + p) * C + c] = xb;
     }
 }
 __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ s, bf16_t* __restrict__ d, int R, int C)
@@ -377,6 +424,16 @@ extern "C" int dc_cfg_ddim_step(const float* eps, float* latents, void* model_in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, st, eps, latents, (bf16_t*)model_in,
                        coef_dev, step_dev, guidance, cfg, B, C, (long long)H * W);
+    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return dc_launch_status();
+}
+extern "C" int dc_cfg_unipc_step(const float* eps, float* latents, float* m0, float* m1, float* last, void* model_in,
+                                 const float* coef_dev, int* step_dev, float guidance, int cfg, int B, int C, int H, int W, void* stream)
+{
+    if (!eps || !latents || !m0 || !m1 || !last || !model_in || !coef_dev || !step_dev || B <= 0) return DC_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(cfg_unipc_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, st, eps, latents, m0, m1, last,
+                       (bf16_t*)model_in, coef_dev, step_dev, guidance, cfg, B, C, (long long)H * W);
     hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return dc_launch_status();
 }

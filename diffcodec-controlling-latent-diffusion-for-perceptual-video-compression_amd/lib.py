@@ -68,6 +68,7 @@ SIGNATURES = {
     "dc_add_bf16": [vp, vp, vp, i64, vp],
     "dc_add_f32": [vp, vp, vp, i64, vp],
     "dc_cfg_ddim_step": [vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp],
+    "dc_cfg_unipc_step": [vp, vp, vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_latents_to_model_input": [vp, vp, f32, i32, i32, i32, i32, i32, vp],
     "dc_postprocess_image": [vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "dc_flow_hw2_resize_scale_f32": [vp, i32, i32, vp, i32, i32, vp],

@@ -614,6 +614,18 @@ def cfg_ddim_step(eps, latents, model_in, coef_dev, step_dev, guidance, cfg):
                         4.0 * eps.numel() + 8.0 * latents.numel() + 2.0 * model_in.numel()))
 
 
+def cfg_unipc_step(eps, latents, m0, m1, last, model_in, coef_dev, step_dev, guidance, cfg):
+    """CFG combine + UniPC corrector / predictor on the fp32 state (dc_cfg_unipc_step); every tensor updated in place."""
+    b, c, h, w = latents.shape
+    for t in (latents, m0, m1, last):
+        _chk(t, F32, "state")
+        assert t.shape == latents.shape and t.is_contiguous()
+    lib.call("dc_cfg_unipc_step", eps.data_ptr(), latents.data_ptr(), m0.data_ptr(), m1.data_ptr(), last.data_ptr(),
+             model_in.data_ptr(), coef_dev.data_ptr(), step_dev.data_ptr(), float(guidance), int(cfg), b, c, h, w, _stream(),
+             meta=_meta("cfg_unipc_kernel (CFG + UniPC step)", f"B={b} {h}x{w}", 20.0 * latents.numel(),
+                        4.0 * eps.numel() + 32.0 * latents.numel() + 2.0 * model_in.numel()))
+
+
 def latents_to_model_input(latents, mul=1.0, rep=1, out=None):
     _chk(latents, F32, "latents")
     b, c, h, w = latents.shape

@@ -20,7 +20,7 @@ import torch
 from . import ops
 from .controlnet import HipDualFlowControlNet
 from . import blocks
-from .scheduler import DDIMScheduler, randn_tensor
+from .scheduler import DDIMScheduler, UniPCMultistepScheduler, randn_tensor
 from .unet import HipUNet2DConditionModel
 from .vae import HipAutoencoderKL
 
@@ -252,8 +252,11 @@ class StableDiffusionDualFlowControlNetPipeline:
             if getattr(net, "needs_warp_cond", False) and warp_cond is None:
                 raise ValueError("a ResControlNet is registered: pass warp_cond [B,3,H,W] (flow_resnet.py:58).")
 
+        # the fused (graph-replayed) loop knows two schedulers: DDIM with eta = 0 (eta > 0 draws noise per step: generic loop) and the
+        # UniPC multistep solver validation.py:37 instantiates (it takes no eta: prepare_extra_step_kwargs drops it)
+        sched_ok = (isinstance(self.scheduler, DDIMScheduler) and not eta) or isinstance(self.scheduler, UniPCMultistepScheduler)
         fused = (isinstance(self.unet, HipUNet2DConditionModel) and all(isinstance(nt_, HipDualFlowControlNet) for nt_ in nets)
-                 and isinstance(self.scheduler, DDIMScheduler) and callback_on_step_end is None and not guess_mode and not eta)   # eta > 0: generic loop
+                 and sched_ok and callback_on_step_end is None and not guess_mode)
         if fused:
             latents = self._denoise_fused(latents, prompt_embeds, negative_prompt_embeds, controlnet_cond, flow_cond, do_cfg,
                                           guidance_scale, base_scales, controlnet_keep, nets, warp_cond)
@@ -322,7 +325,8 @@ class StableDiffusionDualFlowControlNetPipeline:
                                    down_block_additional_residuals=down, mid_block_additional_residual=mid, return_dict=False)[0]
             if do_cfg:                                                                  # :370-372  eps_u + g (eps_t - eps_u)
                 nu, nt_ = (t_.contiguous() for t_ in noise_pred.float().chunk(2, dim=0))
-                noise_pred = ops.lincomb([(1.0 - guidance, nu), (guidance, nt_)])
+                g32 = np.float32(guidance)                                              # 1 - g in fp32, as the fused kernels form it
+                noise_pred = ops.lincomb([(float(np.float32(1.0) - g32), nu), (float(g32), nt_)])
             latents = self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]   # :375
             if callback is not None:                                                    # :378-381
                 loc = dict(latents=latents, prompt_embeds=pe, noise_pred=noise_pred)
@@ -343,6 +347,8 @@ class StableDiffusionDualFlowControlNetPipeline:
             st["lat"] = torch.empty((b, c, h, w), device=device, dtype=torch.float32)
             st["x_in"] = torch.empty(((2 if do_cfg else 1) * b, h, w, c), device=device, dtype=torch.bfloat16)
             st["step"] = torch.zeros(1, device=device, dtype=torch.int32)
+            # multistep state of the UniPC solver (two x0-predictions, the previous predictor's start sample): fp32 like the latents
+            st["ms"] = [torch.zeros((b, c, h, w), device=device, dtype=torch.float32) for _ in range(3)]
             self._graphs.clear()
         st["lat"].copy_(latents)
         st["step"].zero_()
@@ -370,6 +376,7 @@ class StableDiffusionDualFlowControlNetPipeline:
         # CFG duplicates the latents (pipeline.py:313-320): the two batch halves only separate at the first text
         # cross-attention, so the layers before it are computed once (same values, see TransformerBlock.__call__)
         shared = bool(do_cfg and self._cfg_shared)
+        unipc = isinstance(sched, UniPCMultistepScheduler)
 
         def run_nets(scales):
             """every ControlNet's features for this step: [(features[12], mid feature, zero convs, zero mid, scale), ...]"""
@@ -403,7 +410,11 @@ class StableDiffusionDualFlowControlNetPipeline:
                     for t_ in feats + [midf]:
                         t_.record_stream(main)
                 eps = unet.decode_nhwc(sample, list(res), temb, control=ctl)
-            ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
+            if unipc:
+                ops.cfg_unipc_step(eps, st["lat"], st["ms"][0], st["ms"][1], st["ms"][2], st["x_in"], coef, st["step"],
+                                   guidance if do_cfg else 1.0, do_cfg)
+            else:
+                ops.cfg_ddim_step(eps, st["lat"], st["x_in"], coef, st["step"], guidance if do_cfg else 1.0, do_cfg)
 
         nsteps = len(sched.timesteps)
         scales = [tuple(float(bs * keep[i]) for bs in base_scales) for i in range(nsteps)]
@@ -425,7 +436,7 @@ class StableDiffusionDualFlowControlNetPipeline:
             chunk = 1
             while chunk < self._graph_chunk and i + chunk < nsteps and scales[i + chunk] == scale:
                 chunk += 1
-            gkey = (scale, float(guidance), shared, self._dual_stream, chunk)
+            gkey = (scale, float(guidance), shared, self._dual_stream, chunk, unipc)
             g = self._graphs.get(gkey)
             if g is None:
                 torch.cuda.synchronize()

@@ -151,6 +151,8 @@ class UniPCMultistepScheduler:
         self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
         self.solver_order, self.lower_order_final = solver_order, lower_order_final
         self.timesteps = None
+        self.num_inference_steps = None
+        self._coef_dev = None
 
     def set_timesteps(self, num_inference_steps, device=None, **kw):
         n = num_inference_steps
@@ -160,6 +162,8 @@ class UniPCMultistepScheduler:
         sig = ((1 - ac) / ac) ** 0.5
         sig = np.interp(ts, np.arange(0, len(sig)), sig)
         self.sigmas = np.concatenate([sig, [0.0]])
+        if self.timesteps is None or self.num_inference_steps != n:
+            self._coef_dev = None                  # new schedule: new device tables (same one: captured hipGraphs point at them)
         self.timesteps = torch.from_numpy(ts)
         self.num_inference_steps = n
         self.model_outputs = [None] * self.solver_order
@@ -193,6 +197,65 @@ class UniPCMultistepScheduler:
             h_phi_k = h_phi_k / hh - 1.0 / fact if np.isfinite(hh) else -1.0 / fact
         return h_phi_1, b_h, rks, np.array(rr, dtype=np.float64), np.array(bb, dtype=np.float64)
 
+    UNIPC_ROW = 12          # floats per device table row (DC_UNIPC_ROW of csrc/elementwise.hip)
+
+    def _plan(self, i, prev_order, lower_order_nums):
+        """Host scalars of step i given the solver's warm-up state (`this_order` left by the previous step, `lower_order_nums`):
+        dict(ca, ce: x0 = ca x + ce eps; corr: coefficients of (last_sample, m0, m_t, m1 | None) or None; order: the order the
+        predictor runs at (and the next corrector); pred: coefficients of (x, m_t, m1 | None)).  The ONE place the UniPC algebra
+        lives: `step` (generic loop, one dc_lincomb4_f32 launch per update) and `device_tables` (fused loop, dc_cfg_unipc_step)
+        both read it, so the two loops apply the same fp32 coefficients in the same order."""
+        a_i, s_i = self._alpha_sigma(self.sigmas[i])
+        plan = dict(ca=1.0 / a_i, ce=-s_i / a_i, corr=None)
+        if i > 0:                                                                 # ---- corrector (multistep_uni_c_bh_update)
+            order = prev_order
+            a_t, s_t = a_i, s_i
+            a_s, s_s = self._alpha_sigma(self.sigmas[i - 1])
+            lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - (k + 1)])) for k in range(1, order)]
+            h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
+            rhos = np.array([0.5]) if order == 1 else np.linalg.solve(rr, bb)
+            t_x, t_m0, t_mt, t_m1 = s_t / s_s, -a_t * h_phi_1, -a_t * b_h * rhos[-1], None
+            t_m0 += a_t * b_h * rhos[-1]                                            # D1_t = m_t - m0
+            if order == 2:
+                c1 = -a_t * b_h * rhos[0] / rks[0]                                  # corr_res = rho * (m1 - m0) / rk
+                t_m0 -= c1
+                t_m1 = c1
+            plan["corr"] = (t_x, t_m0, t_mt, t_m1)
+        this_order = min(self.solver_order, len(self.timesteps) - i) if self.lower_order_final else self.solver_order
+        order = plan["order"] = min(this_order, lower_order_nums + 1)
+        # ---- predictor (multistep_uni_p_bh_update)
+        a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
+        a_s, s_s = a_i, s_i
+        lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - k])) for k in range(1, order)]
+        h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
+        c_x, c_m0, c_m1 = s_t / s_s, -a_t * h_phi_1, None
+        if order == 2:
+            c = -a_t * b_h * 0.5 / rks[0]                                           # rhos_p = [0.5]; D1 = (m1 - m0) / rk
+            c_m0 -= c
+            c_m1 = c
+        plan["pred"] = (c_x, c_m0, c_m1)
+        return plan
+
+    def coefficients(self):
+        """[steps][UNIPC_ROW] fp32 rows of dc_cfg_unipc_step, the warm-up state machine unrolled over the schedule."""
+        rows, prev_order, lower = [], 1, 0
+        for i in range(len(self.timesteps)):
+            pl = self._plan(i, prev_order, lower)
+            corr, pred = pl["corr"], pl["pred"]
+            flags = (1 if corr is not None else 0) | (2 if corr is not None and corr[3] is not None else 0) | (4 if pred[2] is not None else 0)
+            cz = [0.0 if v is None else float(v) for v in (corr if corr is not None else (0.0, 0.0, 0.0, None))]
+            rows.append([pl["ca"], pl["ce"], float(flags)] + cz + [float(pred[0]), float(pred[1]), 0.0 if pred[2] is None else float(pred[2]), 0.0, 0.0])
+            prev_order = pl["order"]
+            lower = min(lower + 1, self.solver_order)
+        return torch.tensor(rows, dtype=torch.float32)
+
+    def device_tables(self, device):
+        """(coef [steps, UNIPC_ROW] fp32, timesteps [steps] fp32) resident on the device for graph-replayed steps."""
+        if self._coef_dev is None or not DDIMScheduler._same_device(self._coef_dev[0].device, device):
+            self._coef_dev = (self.coefficients().to(device), self.timesteps.float().to(device))
+            self.table_version = getattr(self, "table_version", 0) + 1     # captured hipGraphs key on this counter
+        return self._coef_dev
+
     def step(self, model_output, timestep, sample, return_dict=True, **kw):
         if self.step_index is None:
             idx = (self.timesteps == int(timestep)).nonzero()
@@ -204,44 +267,20 @@ class UniPCMultistepScheduler:
         eps = model_output.float().contiguous()
         if eps.shape != x.shape:
             raise ValueError("model_output and sample must have the same shape")
-        a_i, s_i = self._alpha_sigma(self.sigmas[i])
-        m_t = ops.lincomb([(1.0 / a_i, x), (-s_i / a_i, eps)])                      # convert_model_output: x0 prediction
-        if i > 0 and self.last_sample is not None:                                # ---- corrector (multistep_uni_c_bh_update)
-            order = self.this_order
-            m0 = self.model_outputs[-1]
-            a_t, s_t = self._alpha_sigma(self.sigmas[i])
-            a_s, s_s = self._alpha_sigma(self.sigmas[i - 1])
-            lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - (k + 1)])) for k in range(1, order)]
-            h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
-            rhos = np.array([0.5]) if order == 1 else np.linalg.solve(rr, bb)
-            terms = {"x": s_t / s_s, "m0": -a_t * h_phi_1, "mt": -a_t * b_h * rhos[-1]}
-            terms["m0"] += a_t * b_h * rhos[-1]                                     # D1_t = m_t - m0
-            m1 = None
-            if order == 2:
-                m1 = self.model_outputs[-2]
-                c1 = -a_t * b_h * rhos[0] / rks[0]                                  # corr_res = rho * (m1 - m0) / rk
-                terms["m0"] -= c1
-                terms["m1"] = c1
-            x = ops.lincomb([(terms["x"], self.last_sample), (terms["m0"], m0), (terms["mt"], m_t), (terms.get("m1", 0.0), m1)])
+        pl = self._plan(i, self.this_order, self.lower_order_nums)
+        m_t = ops.lincomb([(pl["ca"], x), (pl["ce"], eps)])                         # convert_model_output: x0 prediction
+        if pl["corr"] is not None and self.last_sample is not None:
+            t_x, t_m0, t_mt, t_m1 = pl["corr"]
+            m1 = self.model_outputs[-2] if t_m1 is not None else None
+            x = ops.lincomb([(t_x, self.last_sample), (t_m0, self.model_outputs[-1]), (t_mt, m_t), (t_m1 if m1 is not None else 0.0, m1)])
         for k in range(self.solver_order - 1):
             self.model_outputs[k] = self.model_outputs[k + 1]
         self.model_outputs[-1] = m_t
-        this_order = min(self.solver_order, len(self.timesteps) - i) if self.lower_order_final else self.solver_order
-        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.this_order = pl["order"]
         self.last_sample = x
-        # ---- predictor (multistep_uni_p_bh_update)
-        order = self.this_order
-        a_t, s_t = self._alpha_sigma(self.sigmas[i + 1])
-        a_s, s_s = self._alpha_sigma(self.sigmas[i])
-        lam_prev = [self._lam(*self._alpha_sigma(self.sigmas[i - k])) for k in range(1, order)]
-        h_phi_1, b_h, rks, rr, bb = self._rhos_and_h(order, self._lam(a_t, s_t), self._lam(a_s, s_s), lam_prev)
-        c_x, c_m0, c_m1, m1 = s_t / s_s, -a_t * h_phi_1, 0.0, None
-        if order == 2:
-            m1 = self.model_outputs[-2]
-            c = -a_t * b_h * 0.5 / rks[0]                                           # rhos_p = [0.5]; D1 = (m1 - m0) / rk
-            c_m0 -= c
-            c_m1 = c
-        prev = ops.lincomb([(c_x, x), (c_m0, m_t), (c_m1, m1)])
+        c_x, c_m0, c_m1 = pl["pred"]
+        m1 = self.model_outputs[-2] if c_m1 is not None else None
+        prev = ops.lincomb([(c_x, x), (c_m0, m_t), (c_m1 if m1 is not None else 0.0, m1)])
         if self.lower_order_nums < self.solver_order:
             self.lower_order_nums += 1
         self.step_index += 1

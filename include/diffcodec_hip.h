@@ -205,6 +205,14 @@ int dc_add_f32(const float* a, const float* b, float* y, long long n, void* stre
  * Also writes the next model input NHWC bf16 [cfg?2B:B][h][w][C]. */
 int dc_cfg_ddim_step(const float* eps, float* latents, void* model_in, const float* coef_dev, int* step_dev,
                      float guidance, int cfg, int B, int C, int H, int W, void* stream);
+/* CFG combine + one UniPCMultistepScheduler.step (the scheduler validation.py:37 instantiates; bh2, predict_x0, order <= 2) in
+ * one pass, for the captured denoising step of pipeline.py:308-385: same operand conventions as dc_cfg_ddim_step; m0 / m1 / last
+ * fp32 [B,C,H,W] scheduler state (the two most recent x0-predictions, the previous predictor's start sample), updated in place;
+ * coef_dev [steps][12] = {1/alpha_i, -sigma_i/alpha_i, flags (1 corrector | 2 corrector uses m1 | 4 predictor uses m1),
+ * corrector coefficients of (last, m0, m_t, m1), predictor coefficients of (x, m_t, m1), 0, 0}.  Arithmetic = the
+ * dc_lincomb4_f32 sequence of the scheduler's generic `step`, bit for bit. */
+int dc_cfg_unipc_step(const float* eps, float* latents, float* m0, float* m1, float* last, void* model_in,
+                      const float* coef_dev, int* step_dev, float guidance, int cfg, int B, int C, int H, int W, void* stream);
 /* latents NCHW f32 [B,C,H,W] * mul -> NHWC bf16 [rep*B,H,W,C] (pipeline.py:313-320, :391 scaling) */
 int dc_latents_to_model_input(const float* latents, void* model_in, float mul, int rep, int B, int C, int H, int W, void* stream);
 /* image_processor.postprocess — pipeline.py:397-398: (x/2+0.5).clamp(0,1); x NHWC f32 [N,H,W,3] -> NCHW f32 and/or NHWC u8 */

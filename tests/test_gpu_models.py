@@ -314,7 +314,7 @@ def test_unipc_scheduler_matches_tensor_form_restatement():
 
 
 def test_pipeline_with_unipc_and_freeu_like_validation_py(small):
-    """validation.py:37,106,132-146 configuration (UniPC + FreeU) through the generic loop: runs, finite, differs from DDIM."""
+    """validation.py:37,106,132-146 configuration (UniPC + FreeU; since round 3 on the fused loop): runs, finite, differs from DDIM."""
     T, pipe, _ = small
     from diffcodec_amd.scheduler import UniPCMultistepScheduler
     cond, flow, pe, npe, lat = _inputs(T)

@@ -132,6 +132,41 @@ def test_conv3x3_nchw_f32(ops, cin, cout, hw, stride, silu):
     close(out, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,hw,stride", [
+    (16, 32, 512, 2),      # 256-wide output: 1 x 128 pixel tiles, the widest stride-2 patch (3 x 257)
+    (32, 32, 256, 1),      # 1 x 128 tiles, 32-channel tile
+    (32, 64, 64, 2),       # 32-wide output: 4 x 32 tiles
+    (64, 64, 128, 1),
+    (64, 160, 128, 2),     # Cout = 160: 32-channel tiles
+    (160, 160, 64, 2),
+    (160, 320, 64, 1),     # 2 x 64 tiles
+    (160, 320, 32, 1),
+    (160, 320, 32, 2),     # 16-wide output: 8 x 16 tiles
+    (320, 640, 16, 2),     # 8x8 output: the 64-pixel tile
+    (640, 1280, 8, 1),
+    (640, 64, 8, 1),
+    (320, 64, 16, 1),
+    (24, 96, 16, 1),       # Cin not a multiple of 16 (three 8-channel chunks)
+])
+def test_conv3x3_nchw_f32_mfma_form(ops, cin, cout, hw, stride):
+    """The extractor layers that take the exact-fp32 MFMA kernel (csrc/conv_f32_mfma.hip: Cin >= 16 in 8-channel chunks, Cout in
+    32-wide tiles, whole pixel tiles) — every pyramid shape of extractors.py:215-262 at its true map size — against F.conv2d in
+    fp32.  The instruction is a k-ordered fmaf chain: same 1e-4 bar as the VALU kernels, and bit-identical run to run."""
+    g = torch.Generator().manual_seed(11)
+    n = 2 if hw <= 256 else 1
+    x = torch.randn(n, cin + 2, hw, hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x[:, 1:1 + cin], w, b, stride=stride, padding=1))
+    pc = ops.PackedConvF32(w, b, DEV)
+    xd = x.to(DEV)[:, 1:1 + cin]                          # channel-slice view (batch stride != Cin*H*W), like cond[:, 3:]
+    out = ops.conv3x3_nchw_f32(xd, pc, stride=stride, silu=True)
+    close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(out, ops.conv3x3_nchw_f32(xd, pc, stride=stride, silu=True))
+    ref_lin = F.conv2d(x[:, 1:1 + cin], w, None, stride=stride, padding=1)        # no bias, no SiLU
+    close(ops.conv3x3_nchw_f32(xd, ops.PackedConvF32(w, None, DEV), stride=stride, silu=False).cpu(), ref_lin, rtol=1e-4, atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------- igemm
 CONV_CASES = [
     # n, h, w, c1, c2, cout, k, stride, pad, upsample

@@ -343,3 +343,84 @@ def test_device_flow_resize_equals_reference_golden(golden_dir):
     for key, (h, w) in (("up_64x96", (64, 96)), ("down_24x20", (24, 20)), ("same_40x56", (40, 56))):
         got = ops.flow_hw2_resize_scale(flow, h, w).cpu()
         torch.testing.assert_close(got, torch.from_numpy(z[key])[0], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- UniPC in the fused (graphed) loop
+@pytest.mark.parametrize("cfg", [True, False])
+def test_fused_unipc_step_is_bit_identical_with_the_generic_scheduler_step(cfg):
+    """`dc_cfg_unipc_step` (CFG combine + corrector + predictor + state rotation from a device coefficient
+    table, one pass) against the scheduler's generic `step` (one dc_lincomb4_f32 launch per update, host coefficients) on a
+    random epsilon sequence: both are built on ONE device function for a*x0 + b*x1 + ..., so every latent of every step —
+    order warm-up and lower-order final step included — must be `torch.equal`.  (The generic step is itself checked against the
+    float64 tensor-form restatement in test_gpu_models.py::test_unipc_scheduler_matches_tensor_form_restatement.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from diffcodec_amd import ops
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    b, c, h, w, guidance = 3, 4, 16, 24, 3.7                      # 3.7: 1 - g is not exact in fp32
+    for n in (2, 6, 40):
+        sg, sf = UniPCMultistepScheduler(), UniPCMultistepScheduler()
+        sg.set_timesteps(n)
+        sf.set_timesteps(n)
+        coef, ttab = sf.device_tables(DEV)
+        assert coef.shape == (n, UniPCMultistepScheduler.UNIPC_ROW) and ttab.shape == (n,)
+        g = torch.Generator().manual_seed(100 + n)
+        x0 = torch.randn(b, c, h, w, generator=g)
+        lat_g = x0.to(DEV)
+        lat_f = x0.to(DEV).clone()
+        ms = [torch.full((b, c, h, w), float("nan"), device=DEV) for _ in range(3)]     # never read before they are written
+        x_in = torch.empty(((2 if cfg else 1) * b, h, w, c), device=DEV, dtype=torch.bfloat16)
+        step = torch.zeros(1, device=DEV, dtype=torch.int32)
+        for i, t in enumerate(sg.timesteps.tolist()):
+            eps = torch.randn((2 if cfg else 1) * b, h, w, c, generator=g).to(DEV)            # NHWC fp32, like conv_out's output
+            e = eps.permute(0, 3, 1, 2).contiguous()
+            if cfg:
+                nu, nt = (v.contiguous() for v in e.chunk(2))
+                g32 = np.float32(guidance)
+                e = ops.lincomb([(float(np.float32(1.0) - g32), nu), (float(g32), nt)])
+            lat_g = sg.step(e, t, lat_g, return_dict=False)[0]
+            ops.cfg_unipc_step(eps, lat_f, ms[0], ms[1], ms[2], x_in, coef, step, guidance if cfg else 1.0, cfg)
+            assert torch.equal(lat_f, lat_g), (n, i)
+            assert torch.isfinite(lat_f).all()
+            want_in = lat_f.permute(0, 2, 3, 1).to(torch.bfloat16)
+            assert torch.equal(x_in[:b], want_in) and (not cfg or torch.equal(x_in[b:], want_in))
+        assert int(step.item()) == n
+
+
+def test_pipeline_unipc_freeu_fused_loop_graphs_and_generic_loop(small):
+    """The configuration validation.py:37,106,132-146 runs (UniPC multistep + FreeU + CFG), on the fast path: the fused loop
+    (eager), its hipGraph replay (one captured step serves every step: the coefficients are indexed by the device step counter)
+    and the generic loop (module calls + scheduler.step; forced by a callback).  Eager fused == graph replay bit for bit; fused vs
+    generic differ only by the bf16 round trips of the ControlNet residuals (same bar as the DDIM pair of test_gpu_models.py)."""
+    T, pipe, _ = small
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    cond, flow = synth_controls(1, 256)
+    pe, npe = synth_text(1, dim=T.SMALL_UNET["cross_attention_dim"])
+    lat = synth_latents(1, 256)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+              num_inference_steps=6, guidance_scale=3.5, controlnet_conditioning_scale=1.35, output_type="pt")
+    ddim = pipe.scheduler
+    base = pipe(**kw).images.float().cpu()
+    pipe.scheduler = UniPCMultistepScheduler()
+    pipe.enable_freeu(s1=0.9, s2=0.2, b1=1.2, b2=1.4)
+    try:
+        fused = pipe(**kw).images.float().cpu()
+        seen = []
+        generic = pipe(**kw, callback_on_step_end=lambda p, i, t, d: (seen.append(int(t)), d)[1]).images.float().cpu()
+        assert seen == pipe.scheduler.timesteps.tolist() and len(seen) == 6
+        pipe.enable_hip_graphs(True)
+        try:
+            graph1 = pipe(**kw).images.float().cpu()
+            graph2 = pipe(**kw).images.float().cpu()
+            n_graphs = len(pipe._graphs)
+        finally:
+            pipe.enable_hip_graphs(False)
+    finally:
+        pipe.disable_freeu()
+        pipe.scheduler = ddim
+    assert torch.isfinite(fused).all() and 0.0 <= fused.min() and fused.max() <= 1.0
+    assert torch.equal(graph1, fused) and torch.equal(graph2, fused)
+    assert n_graphs == 1                                                     # one captured step for all six
+    assert T.psnr(fused, generic) > 35.0, T.psnr(fused, generic)
+    assert T.psnr(fused, base) < 40.0                                        # and it is not the DDIM result
