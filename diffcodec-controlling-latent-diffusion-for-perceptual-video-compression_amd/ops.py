@@ -245,7 +245,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     if lib.TIMER is not None:
         kk = pc.cin * k * k
         if k == 1 and gn_ab is None:
-            fam = "gemm_dma_kernel (1x1 conv / linear, LDS-DMA GEMM)"
+            fam = "gemm_dma_kernel + gemm_wide_kernel + gemm_rowpanel_kernel (1x1 conv / linear GEMM family)"
         elif k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample):
             fam = "conv3x3_tile_kernel (3x3 stride-1 halo-tile conv)"
         else:
@@ -292,7 +292,7 @@ def conv3x3_nchw_f32(x, pc, stride=1, silu=False):
     y = torch.empty((n, pc.cout, ho, wo), device=x.device, dtype=F32)
     lib.call("dc_conv3x3_nchw_f32", x.data_ptr(), x.stride(0), pc.w.data_ptr(), _ptr(pc.bias), y.data_ptr(), n, c, h, w,
              pc.cout, stride, int(silu), _stream(),
-             meta=_meta("conv3x3_nchw_f32_kernel (fp32 extractor conv)", f"N={n} {c}->{pc.cout} {h}x{w} s{stride}",
+             meta=_meta("conv3x3_f32_mfma_kernel + conv3x3_nchw_f32_kernel (fp32 extractor conv: MFMA form / VALU form)", f"N={n} {c}->{pc.cout} {h}x{w} s{stride}",
                         2.0 * y.numel() * c * 9, 4.0 * (n * c * h * w + y.numel() + pc.w.numel())))
     return y
 

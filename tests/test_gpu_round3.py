@@ -153,12 +153,16 @@ def test_c5_full_size_window_row_vs_oracle_2_steps(full, record):
 # ------------------------------------------------------------------------------------------- shared CFG prefix: exact
 def test_cfg_shared_prefix_is_bit_exact_when_the_tile_choice_is_row_count_independent(full):
     """DESIGN §3 item 5 says the shared prefix computes 'the same values'.  Every kernel on the prefix is row-wise deterministic
-    for a FIXED tile / split-K choice; the choice depends on the row count only below ~512 tiles.  At model batch 16 (8 frames)
-    both the half batch (32,768 rows at 64x64) and the full batch take the 128-row, unsplit tiles, so the ControlNet's
-    features and the U-Net's noise prediction must be bit-identical with and without the sharing."""
+    for a FIXED kernel / tile / split-K choice, and that choice depends on the row count only: below ~512 tiles (split-K, small
+    tiles) and at 65,536 rows, where the K = 320 linears move from the 128-row tile kernel to the row-panel kernel (same bf16
+    outputs bit for bit, but its LayerNorm row statistics are summed whole-row instead of per 80-column slice, i.e. rounded
+    differently in the last place).  At the bench's model batch 32 (16 frames) both the half batch (65,536 rows at 64x64) and the
+    full batch (131,072) take the row-panel kernel and unsplit tiles everywhere, so the ControlNet's features and the U-Net's
+    noise prediction must be bit-identical with and without the sharing.  (At model batch 16 the two sides straddle the 65,536-row
+    switch: first GPU run of this test after the row-panel kernel landed.)"""
     T, pipe, _ = full
     from diffcodec_amd.synthetic import synth_controls, synth_text
-    b = 8
+    b = 16
     cond, flow = synth_controls(b, 512, seed=77)
     pe, npe = synth_text(b)
     ctx = torch.cat([npe, pe], 0).to(DEV, torch.bfloat16).contiguous()
