@@ -95,7 +95,7 @@ def cpu_baseline(sds, threads, device_decode=None):
 
 # PMC reference shape per kernel family (tools/pmc_conv.py launches exactly these; algorithmic bytes = inputs + weights + output)
 # value: (shape label, algorithmic bytes, launch grid in threads of that shape — what tells a family's PMC rows apart)
-PMC_SHAPES = {"gemm_": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320)", 167976960, 524288),
+PMC_SHAPES = {"gemm_": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320; gemm_rowpanel_kernel, 512 panels x 512 threads)", 167976960, 262144),
               "conv3x3_tile_kernel": ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360, 524288),
               "attn_kernel": ("attention B=32 H=8 N=4096 d=40", 335544320, 1048576)}
 PMC_FILES = ("r03_pmc_summary.json", "r02_pmc_summary.json")

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Developer tool (GPU box): the rocprofv3 summaries committed under profiles/ for a round.
-#   tools/collect_profiles.sh r02        -> gpurun_out/<tag>_*  (copy the summaries into profiles/ afterwards)
+#   tools/collect_profiles.sh r03        -> gpurun_out/<tag>_*  (copy the summaries into profiles/ afterwards)
 # kernel-trace/stats and every --pmc pass are SEPARATE runs (never combined with other trace domains).
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_f16 -- python3 bench.py --steps 1 --warmup 0 --no-graphs --no-cpu-baseline --no-roofline --dual-stream 0 > $out/${tag}_f16.log 2>&1

@@ -12,6 +12,16 @@ for (h, c, cout, k) in [(64, 320, 320, 3), (32, 640, 640, 3), (64, 320, 320, 1)]
         y = ops.conv(x, pc)
     torch.cuda.synchronize()
     print(f"shape n={n} {h}x{h} {c}->{cout} k{k}: algorithmic bytes = {x.numel()*2 + pc.w.numel()*2 + y.numel()*2} M={n*h*h} grid_threads={'?'}")
+# the K = 320 transformer linears on the row-panel kernel: folded-LayerNorm QKV (N = 960) and GEGLU (N = 2560)
+xr = torch.randn(1, n * 4096, 320, generator=g).to("cuda", torch.bfloat16)
+mr = ops.ln_finalize(ops.row_stats(xr), 320, 1e-5)
+for (cout, geglu) in [(960, False), (2560, True)]:
+    lnp = (1 + 0.1 * torch.randn(320, generator=g), 0.1 * torch.randn(320, generator=g), 1e-5)
+    pcl = ops.PackedConv(torch.randn(cout, 320, generator=g) / math.sqrt(320), torch.zeros(cout), "cuda", geglu=geglu, ln=lnp)
+    for _ in range(5):
+        yl = ops.linear(xr, pcl, ln_stats=mr)
+    torch.cuda.synchronize()
+    print(f"shape rowpanel M={n*4096} K=320 N={cout} geglu={int(geglu)}: algorithmic bytes = {xr.numel()*2 + pcl.w.numel()*2 + yl.numel()*2}")
 # flash attention, d = 40, 64x64 tokens (the third family by time)
 q = torch.randn(n, 4096, 960, generator=g).to("cuda", torch.bfloat16)
 for _ in range(3):
