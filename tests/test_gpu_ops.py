@@ -78,6 +78,29 @@ def test_splat_pathological_flows(ops):
         close(ops.splat_soft(x.to(DEV), flow.to(DEV), m.to(DEV)).cpu(), S.softsplat(x, flow, m, "soft"), rtol=1e-4, atol=1e-5)
 
 
+def test_splat_fully_collapsed_flow_is_bounded(ops):
+    """the deterministic gather ranks a cell's sources by counting (k^2 compares for a k-way collision) and one thread
+    walks a target's whole source list.  Worst case: EVERY source of a full-size 512x512 map lands in one cell (k = 262,144:
+    7e10 compares, four targets x C threads walking 262,144-long lists).  All lanes of a wave read the same list element, so the
+    rank pass is one broadcast load per step and the job stays in the tens of milliseconds — asserted here with a wide margin
+    (a slow-down to seconds would make a pathological flow look like a hang on a shared box), still bit-exact with the oracle."""
+    import time
+    from oracle import splat as S
+    h = w = 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, h, w, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    flow = torch.stack([200.25 - xs, 100.5 - ys])[None].contiguous()
+    xd, fd = x.to(DEV), flow.to(DEV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = ops.splat_sum(xd, fd)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert dt < 3.0, f"collapsed 512x512 splat took {dt:.2f} s"
+    assert torch.equal(out.cpu(), S.splat_sum(x, flow))
+
+
 def test_occlusion_mask_and_flow_resize(ops):
     from oracle import control_ref as C
     g = torch.Generator().manual_seed(1)

@@ -186,3 +186,38 @@ def test_randn_tensor_follows_diffusers_generator_rules():
     with pytest.raises(ValueError, match="list of generators of length 3"):
         randn_tensor((2, 4, 8, 8), gens + gens[:1], "cpu")
     assert randn_tensor((1, 4, 8, 8), None, "cpu", torch.bfloat16).dtype == torch.bfloat16
+
+
+def test_unipc_device_table_reproduces_the_tensor_form_restatement():
+    """The coefficient rows the fused loop hands to dc_cfg_unipc_step (scheduler.UniPCMultistepScheduler.coefficients: the order
+    warm-up state machine unrolled, flags + corrector / predictor coefficients per step), applied with the kernel's update rule
+    in float64 on the host, against the oracle's tensor-form UniPC (written independently, in the library's D1s / rhos form):
+    every latent of 2-, 5-, 20- and 40-step schedules.  No GPU: this pins the TABLE; the kernel's arithmetic is pinned to the
+    generic scheduler step bit for bit by tests/test_gpu_round3.py."""
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    from oracle.pipeline_ref import UniPCRef
+    for n in (2, 5, 20, 40):
+        s, r = UniPCMultistepScheduler(), UniPCRef()
+        s.set_timesteps(n)
+        r.set_timesteps(n)
+        rows = s.coefficients().double()
+        assert rows.shape == (n, UniPCMultistepScheduler.UNIPC_ROW)
+        flags = rows[:, 2].long().tolist()
+        assert flags[0] == (0 if n == 1 else 0) and all(f & 1 for f in flags[1:])          # no corrector on the first step only
+        assert flags[-1] & 4 == 0                                                            # lower_order_final: last predictor is order 1
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+        xr = x.clone()
+        m0 = m1 = last = torch.zeros_like(x)
+        for i, t in enumerate(s.timesteps.tolist()):
+            eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+            c = rows[i]
+            f = int(c[2])
+            mt = c[0] * x + c[1] * eps
+            xc = x
+            if f & 1:
+                xc = c[3] * last + c[4] * m0 + c[5] * mt + (c[6] * m1 if f & 2 else 0.0)
+            last, m1, m0 = xc, m0, mt
+            x = c[7] * xc + c[8] * mt + (c[9] * m1 if f & 4 else 0.0)
+            xr = r.step(eps, t, xr)
+            torch.testing.assert_close(x, xr.double(), rtol=2e-5, atol=2e-5)     # the rows are fp32
