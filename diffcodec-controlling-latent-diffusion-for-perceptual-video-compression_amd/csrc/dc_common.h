@@ -92,6 +92,22 @@ __device__ __forceinline__ f32x4 dc_ln_fold(f32x4 v, float mean, float rstd, f32
     return o;
 }
 
+// (sum, sum of squares) partials of one row -> (mean, rstd) of a LayerNorm over 1 / inv_c channels: the ONE definition behind
+// dc_ln_finalize and the consumers that finalize in their prologue (dc_conv_desc.ln_parts), so both give the same bits.
+__device__ __forceinline__ void dc_ln_mean_rstd(const float* __restrict__ row_partials, int parts, float inv_c, float eps, float& mean,
+                                                float& rstd)
+{
+#pragma clang fp contract(off)
+    float a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < parts; ++i) {                       // independent 8-byte loads, summed in index order
+        const float2 v = ((const float2*)row_partials)[i];
+        a1 += v.x;
+        a2 += v.y;
+    }
+    mean = a1 * inv_c;
+    rstd = rsqrtf(fmaxf(a2 * inv_c - mean * mean, 0.f) + eps);
+}
+
 __device__ __forceinline__ float dc_wave_sum(float v)
 {
 #pragma unroll

@@ -549,6 +549,17 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
     {
         const int epi = epi_mode(d);
         if (dc_gemm_rowpanel_wanted(d, epi)) return dc_gemm_rowpanel_launch(d, epi, st);
+        if (d.ln_stats && d.ln_parts > 0) {
+            // raw LayerNorm partials and a kernel whose waves do not own whole rows: the finalize pass runs here, into the
+            // caller's scratch, and the launch proceeds on (mean, rstd) pairs — the same bits as finalizing beforehand
+            if (!d.ln_scratch) return DC_ERR_INVALID;
+            const int rc = dc_ln_finalize(d.ln_stats, d.ln_scratch, M, d.ln_parts, d.C1 + d.C2, d.ln_eps, (void*)st);
+            if (rc != DC_OK) return rc;
+            dc_conv_desc q = d;
+            q.ln_stats = d.ln_scratch;
+            q.ln_parts = 0;
+            return dc_gemm_dma_launch(q, st);
+        }
         if (dc_gemm_wide_wanted(d, epi)) return dc_gemm_wide_launch(d, epi, st);
     }
     if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;

@@ -103,7 +103,16 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
     f32x2 ln_mr[RP_TM];
     if (e_ln) {
 #pragma unroll
-        for (int tm = 0; tm < RP_TM; ++tm) ln_mr[tm] = *(const f32x2*)(d.ln_stats + (mw + tm * 16 + fr) * 2);
+        for (int tm = 0; tm < RP_TM; ++tm) {
+            const long long m = mw + tm * 16 + fr;
+            if (d.ln_parts > 0) {                                   // raw partials: the finalize pass folded into this prologue
+                float mean, rstd;
+                dc_ln_mean_rstd(d.ln_stats + m * d.ln_parts * 2, d.ln_parts, 1.0f / (float)RP_K, d.ln_eps, mean, rstd);
+                ln_mr[tm] = f32x2{mean, rstd};
+            } else {
+                ln_mr[tm] = *(const f32x2*)(d.ln_stats + m * 2);
+            }
+        }
     }
 
     // ---- W stage image in LDS: row n (64) x 640 B, 16-byte chunk c of row n stored at chunk position c ^ (n & 7) (the XOR

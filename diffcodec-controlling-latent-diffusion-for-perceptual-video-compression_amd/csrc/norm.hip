@@ -425,18 +425,8 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 {
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
     if (row >= M) return;
-    const float2* p = (const float2*)(partials + row * parts * 2);
-    float a1 = 0.f, a2 = 0.f;
-#pragma unroll 8
-    for (int i = 0; i < parts; ++i) {                       // independent 8-byte loads, summed in index order
-        const float2 v = p[i];
-        a1 += v.x;
-        a2 += v.y;
-    }
-    const float mean = a1 * inv_c;
     float2 o;
-    o.x = mean;
-    o.y = rsqrtf(fmaxf(a2 * inv_c - mean * mean, 0.f) + eps);
+    dc_ln_mean_rstd(partials + row * parts * 2, parts, inv_c, eps, o.x, o.y);
     *(float2*)(mr + row * 2) = o;
 }
 

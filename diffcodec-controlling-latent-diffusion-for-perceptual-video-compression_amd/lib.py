@@ -22,6 +22,7 @@ class ConvDesc(ctypes.Structure):
         ("gn_silu", i32), ("epilogue", i32), ("out_f32", i32), ("out_scale", f32), ("splitk", i32), ("gn_batch", i32),
         ("act", i32), ("row_add_stride", i64),
         ("ln_stats", vp), ("ln_colsum", vp), ("stats_out", vp), ("gn_part_out", vp),
+        ("ln_parts", i32), ("ln_eps", f32), ("ln_scratch", vp),
     ]
 
 

@@ -157,12 +157,15 @@ def ln_finalize(partials, c, eps):
 
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
          upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None, ln_stats=None, stats_out=None,
-         gn_part=False):
+         gn_part=False, ln_partials=None):
     """F.conv2d (k=1|3) / nn.Linear on NHWC bf16 with the fusions of `dc_conv_desc`.  `out`: optional preallocated
     contiguous destination (e.g. one batch half of a larger buffer) on the igemm path.
     ln_stats: (mean, rstd) [M, 2] of the rows of x1 (`ln_finalize`) for a `pc` built with ln=(gamma, beta, eps): LayerNorm folded
     into this linear.
     stats_out: fp32 [M, row_stats_parts(cout), 2] to receive the row statistics of the OUTPUT (the next block's ln_stats).
+    ln_partials: (partials [M, parts, 2], eps) — the RAW row statistics a producer's `stats_out` (or `row_stats`) wrote, instead of
+    `ln_stats`: the LayerNorm finalize pass is folded into this launch (dc_conv_desc.ln_parts; same bits as
+    `ln_stats=ln_finalize(partials, cin, eps)`), which saves a launch per LayerNorm wherever the row-panel kernel takes the GEMM.
     gn_part: ask the epilogue for the GroupNorm partial sums of the OUTPUT (dc_conv_desc.gn_part_out); when the launch can
     emit them the returned tensor carries them as `.gn_part` ([chunks, N, Cout, 2] fp32) and `group_norm_ab` skips its read
     pass over the tensor; otherwise the request is ignored and `group_norm_ab` measures the tensor as before."""
@@ -204,6 +207,15 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         out = out.view(n, ho, wo, cout_eff)
     m = n * ho * wo
     kt = (9 if k == 3 else 1) * (pc.cin // 64)
+    ln_parts, ln_eps, ln_scratch = 0, 0.0, None
+    if ln_partials is not None:
+        if ln_stats is not None:
+            raise ValueError("pass ln_stats or ln_partials, not both")
+        ln_stats, ln_eps = ln_partials
+        _chk(ln_stats, F32, "ln_partials")
+        assert ln_stats.dim() == 3 and ln_stats.shape[0] == m and ln_stats.shape[2] == 2
+        ln_parts = int(ln_stats.shape[1])
+        ln_scratch = torch.empty((m, 2), device=x1.device, dtype=F32)     # used only when the chosen kernel cannot fold the finalize
     if ln_stats is not None or stats_out is not None:
         splitk = 1                          # the folded LayerNorm / row statistics live in the unsplit bf16 epilogue
     if splitk is None:
@@ -220,7 +232,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         raise ValueError("ln_stats must be given exactly when the weights carry a folded LayerNorm")
     if ln_stats is not None:
         _chk(ln_stats, F32, "ln_stats")
-        assert tuple(ln_stats.shape) == (m, 2) and x2 is None and gn_ab is None and k == 1
+        assert (ln_parts > 0 or tuple(ln_stats.shape) == (m, 2)) and x2 is None and gn_ab is None and k == 1
     if stats_out is not None:
         _chk(stats_out, F32, "stats_out")
         assert tuple(stats_out.shape) == (m, row_stats_parts(pc.cout), 2) and k == 1 and not pc.geglu and not out_f32
@@ -234,7 +246,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
                  Ho=ho, Wo=wo, gn_silu=int(gn_silu), epilogue=1 if pc.geglu else 0, out_f32=int(out_f32),
                  out_scale=float(out_scale), splitk=int(splitk), gn_batch=0 if gn_ab is None else gn_ab.shape[0],
                  act=int(act), row_add_stride=int(ras), ln_stats=_ptr(ln_stats), ln_colsum=_ptr(pc.colsum if ln_stats is not None else None),
-                 stats_out=_ptr(stats_out), gn_part_out=0)
+                 stats_out=_ptr(stats_out), gn_part_out=0, ln_parts=ln_parts, ln_eps=float(ln_eps), ln_scratch=_ptr(ln_scratch))
     part = None
     if gn_part and GN_EPILOGUE_STATS and not out_f32 and not pc.geglu and splitk == 1 and ln_stats is None:
         chunks = lib.load().dc_conv_gn_part_chunks(d)

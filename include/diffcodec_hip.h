@@ -112,6 +112,15 @@ typedef struct dc_conv_desc {
      * (sum, sum of squares) — the operand dc_gn_finalize takes — instead of a separate read pass over the tensor.  NULL = off.
      * Only the launches for which dc_conv_gn_part_chunks returns > 0 accept it. */
     float* gn_part_out;
+    /* The LayerNorm finalize folded into the consumer (round 3).  ln_parts > 0: `ln_stats` holds the RAW partials
+     * [M][ln_parts][2] (sum, sum of squares) exactly as a producer's `stats_out` (or dc_row_stats_bf16, parts = 1) wrote them, and
+     * the launch forms (mean, rstd) over the C1 + C2 input channels itself, with dc_ln_finalize's arithmetic and `ln_eps`: kernels
+     * whose waves own whole rows do it in their prologue; for the other kernels the launcher runs the dc_ln_finalize pass into
+     * `ln_scratch` ([M][2] floats, caller-owned, required) first — either way the same bits as finalizing beforehand.
+     * ln_parts == 0: `ln_stats` is the finalized [M][2] (mean, rstd). */
+    int ln_parts;
+    float ln_eps;
+    float* ln_scratch;
 } dc_conv_desc;
 int dc_conv_igemm_bf16(const dc_conv_desc* desc, void* stream);
 /* Workspace bytes needed for splitk>1 (0 otherwise). */

@@ -287,9 +287,10 @@ def test_checkpoint_seam_synthetic_diffusers_directory(small, tmp_path):
     (base / "vae" / "config.json").write_text(json.dumps(dict(
         _class_name="AutoencoderKL", block_out_channels=list(vcfg["block_out_channels"]), layers_per_block=2, latent_channels=4,
         in_channels=3, out_channels=3, norm_num_groups=32)))                       # no scaling_factor entry, as in SD-1.5's file
-    # weights are bf16-exact, hence fp16-exact for normal magnitudes: storing every other tensor as fp16 loses nothing
+    # weights are bf16-exact, hence fp16-exact wherever they are fp16-normal (|w| >= 6.1e-5); the few smaller ones land on the
+    # fp16 subnormal grid (steps of 6e-8) — the loaded dict, not the original, is what the oracle is fed below
     u_store = {k: (v.half() if i % 2 else v.clone()) for i, (k, v) in enumerate(usd.items())}
-    assert all(torch.equal(u_store[k].float(), usd[k]) for k in usd)
+    assert max((u_store[k].float() - usd[k]).abs().max().item() for k in usd) < 6.1e-8
     save_file(u_store, str(base / "unet" / "diffusion_pytorch_model.safetensors"))
     legacy = {}
     for k, v in vsd.items():

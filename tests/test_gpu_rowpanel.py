@@ -159,3 +159,26 @@ def test_full_batch_shape_131072_rows(ops):
     big = ops.linear(x, pc)
     small = torch.cat([ops.linear(x[:, i:i + CH], pc) for i in range(0, m, CH)], 1)
     assert torch.equal(big, small)
+
+
+@pytest.mark.parametrize("m", [M, CH])
+def test_layernorm_finalize_folded_into_the_consumer(ops, m):
+    """dc_conv_desc.ln_parts: the consumer takes the producer's RAW row partials and forms (mean, rstd) itself — in its prologue
+    on the row-panel kernel (m = 65,536), through the finalize pass the dispatcher launches into the caller's scratch on the tile
+    kernels (m = 16,384).  One device function holds the arithmetic, so both equal `ln_stats=ln_finalize(partials)` bit for bit."""
+    g = torch.Generator().manual_seed(21)
+    x = _rows(g, m, K, 1.5)
+    w0 = bf(torch.randn(K, K, generator=g) / math.sqrt(K))
+    parts = ops.row_stats_parts(K)
+    st = torch.empty((m, parts, 2), device=DEV)
+    t = ops.linear(x, ops.PackedConv(w0, torch.randn(K, generator=g), DEV), residual=x, stats_out=st)   # a producer with statistics
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    for n_out, geglu in ((960, False), (2560, True)):
+        pc = ops.PackedConv(torch.randn(n_out, K, generator=g) / math.sqrt(K), 0.1 * torch.randn(n_out, generator=g), DEV,
+                            geglu=geglu, ln=(gamma, beta, 1e-5))
+        a = ops.linear(t, pc, ln_stats=ops.ln_finalize(st, K, 1e-5))
+        b = ops.linear(t, pc, ln_partials=(st, 1e-5))
+        assert torch.equal(a, b)
+    one = ops.row_stats(t)                                                       # the single-part form (row_stats)
+    pc = ops.PackedConv(torch.randn(320, K, generator=g) / math.sqrt(K), None, DEV, ln=(gamma, beta, 1e-5))
+    assert torch.equal(ops.linear(t, pc, ln_stats=ops.ln_finalize(one, K, 1e-5)), ops.linear(t, pc, ln_partials=(one, 1e-5)))
