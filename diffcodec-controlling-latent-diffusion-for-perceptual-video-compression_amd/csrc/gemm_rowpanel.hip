@@ -48,6 +48,14 @@
 #define RP_STAMP_AT(i)
 #endif
 
+// Developer experiments (scratch builds of tools/build_dev.sh only; wrong results): which resource bounds a launch?
+#ifndef DC_EXP_RP_NOSTORE
+#define DC_EXP_RP_NOSTORE 0     // 1: the row stores are compiled out (everything else, staging reads included, stays)
+#endif
+#ifndef DC_EXP_RP_NOMFMA
+#define DC_EXP_RP_NOMFMA 0      // 1: one MFMA per k-step instead of eight
+#endif
+
 namespace {
 
 typedef const void __attribute__((address_space(1))) * gptr_t;
@@ -215,7 +223,10 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
             for (int tn = 0; tn < RP_TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < RP_TM; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k & 1][tn], xf[tm][k], acc[tn][tm], 0, 0, 0);
+                    if (!DC_EXP_RP_NOMFMA || (tn == 0 && tm == 0))
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k & 1][tn], xf[tm][k], acc[tn][tm], 0, 0, 0);
+                    else
+                        asm volatile("" ::"v"(wf[k & 1][tn]), "v"(xf[tm][k]));      // operands stay fetched
             if (k + 1 < RP_KS) __builtin_amdgcn_sched_group_barrier(0x100, RP_TN, 0);       // the next step's reads first ...
             __builtin_amdgcn_sched_group_barrier(0x008, RP_TN * RP_TM, 0);                  // ... then this step's MFMAs
         }
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
                 const int row = (lane >> 2) + 16 * i, c = lane & 3;
                 u32x4 v = *(const u32x4*)(stg + row * 64 + ((c ^ ((row >> 1) & 3)) << 4));
                 if ((row >> 3) & 1) v = u32x4{v[2], v[3], v[0], v[1]};
-                *(u32x4*)(o + (mw + row) * out_cols + s * (RP_SC / 2) + c * 8) = v;
+                if (!DC_EXP_RP_NOSTORE || v[0] == 0x12345678u) *(u32x4*)(o + (mw + row) * out_cols + s * (RP_SC / 2) + c * 8) = v;
             }
         } else {
 #pragma unroll
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
                 const int row = (lane >> 3) + 8 * i, c = lane & 7;
                 u32x4 v = *(const u32x4*)(stg + row * 128 + ((c ^ (row & 7)) << 4));
                 if (i & 1) v = u32x4{v[2], v[3], v[0], v[1]};
-                *(u32x4*)(o + (mw + row) * out_cols + s * RP_SC + c * 8) = v;
+                if (!DC_EXP_RP_NOSTORE || v[0] == 0x12345678u) *(u32x4*)(o + (mw + row) * out_cols + s * RP_SC + c * 8) = v;
             }
         }
         RP_STAMP_AT(4 + 3 * s);
