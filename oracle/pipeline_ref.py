@@ -137,11 +137,12 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
                  negative_prompt_embeds, latents, num_inference_steps=20, guidance_scale=7.5,
                  controlnet_conditioning_scale=1.0, output_type="pt", hoist=True, return_latents=False,
                  control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None,
-                 res_cn_sd=None, warp_cond=None, res_conditioning_scale=None):
+                 res_cn_sd=None, warp_cond=None, res_conditioning_scale=None, scheduler="ddim", freeu=None):
     """pipeline.py:144-404, `prompt_embeds=` path.  hoist=True computes the step-invariant pyramid once
     (identical values to recomputing it every step as the reference does, flownet.py:78)."""
     do_cfg = guidance_scale is not None and guidance_scale > 1.0            # pipeline.py:202
-    sched = DDIMRef()
+    # scheduler="unipc" + freeu=dict(s1, s2, b1, b2): the configuration validation.py:37,106 runs (UniPCRef / apply_freeu above)
+    sched = UniPCRef() if scheduler == "unipc" else DDIMRef()
     sched.set_timesteps(num_inference_steps)
     ctx = torch.cat([negative_prompt_embeds, prompt_embeds], 0) if do_cfg else prompt_embeds   # :234-236
     latents = latents.float() * sched.init_noise_sigma
@@ -171,12 +172,12 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
             d2, m2 = M.dualflow_controlnet_forward(res_cn_sd, unet_cfg, x_in, t, ctx, cc, fc, res_conditioning_scale * keep,
                                                    pyramid=p2, residual_variant=True)
             down, mid = [a_ + b_ for a_, b_ in zip(down, d2)], mid + m2
-        eps = M.unet_forward(unet_sd, unet_cfg, x_in, t, ctx, down, mid)   # :358-367
+        eps = M.unet_forward(unet_sd, unet_cfg, x_in, t, ctx, down, mid, freeu=freeu)   # :358-367
         if do_cfg:
             eu, et = eps.chunk(2)
             eps = eu + guidance_scale * (et - eu)                           # :370-372
         noise = torch.randn(tuple(eps.shape), generator=generator, dtype=torch.float32) if eta else None   # :289 -> step(eta=, generator=)
-        latents = sched.step(eps, t, latents, eta, noise)                   # :375
+        latents = sched.step(eps, t, latents).float() if scheduler == "unipc" else sched.step(eps, t, latents, eta, noise)   # :375
     if output_type == "latent" or return_latents and vae_sd is None:
         return latents
     img = M.vae_decode(vae_sd, vae_cfg, latents / vae_cfg["scaling_factor"])   # :391

@@ -429,3 +429,38 @@ def test_pipeline_unipc_freeu_fused_loop_graphs_and_generic_loop(small):
     assert n_graphs == 1                                                     # one captured step for all six
     assert T.psnr(fused, generic) > 35.0, T.psnr(fused, generic)
     assert T.psnr(fused, base) < 40.0                                        # and it is not the DDIM result
+
+
+def test_pipeline_unipc_freeu_vs_oracle_small_and_full(small, full, record):
+    """The validation.py configuration end to end against the INDEPENDENT fp32 oracle (oracle/pipeline_ref.decode_frame with
+    scheduler='unipc', freeu=...: the tensor-form UniPC restatement and apply_freeu inside the restated U-Net): the small pipeline at
+    6 steps and the true SD-1.5 widths at 512x512, 8 steps — the fused loop's scheduler kernel, FreeU kernels and graph replay all
+    sit between the two.  Measured 44.3 dB (small) and 45.6 dB (full widths); the bars sit 3 dB under (the decode is deterministic)."""
+    from diffcodec_amd import weights as W
+    from diffcodec_amd.scheduler import UniPCMultistepScheduler
+    from diffcodec_amd.synthetic import synth_controls, synth_latents, synth_text
+    from oracle import pipeline_ref as R
+    fu = dict(s1=0.9, s2=0.2, b1=1.2, b2=1.4)
+    for tag, (T, pipe, (usd, csd, vsd)), ucfg, vcfg, size, steps, bar in (
+            ("small", small, None, None, 256, 6, 41.0), ("full", full, W.SD15_UNET_CONFIG, W.SD15_VAE_CONFIG, 512, 8, 42.0)):   # measured 44.3 / 45.6 dB
+        ucfg = T.SMALL_UNET if ucfg is None else ucfg
+        vcfg = T.SMALL_VAE if vcfg is None else vcfg
+        cond, flow = synth_controls(1, size)
+        pe, npe = synth_text(1, dim=ucfg["cross_attention_dim"])
+        lat = synth_latents(1, size)
+        kw = dict(num_inference_steps=steps, guidance_scale=5.0, controlnet_conditioning_scale=1.35)
+        ddim = pipe.scheduler
+        pipe.scheduler = UniPCMultistepScheduler()
+        pipe.enable_freeu(**fu)
+        pipe.enable_hip_graphs(True)
+        try:
+            img = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat,
+                       output_type="pt", **kw).images.float().cpu()
+        finally:
+            pipe.enable_hip_graphs(False)
+            pipe.disable_freeu()
+            pipe.scheduler = ddim
+        ref = R.decode_frame(usd, csd, vsd, ucfg, vcfg, cond, flow, pe, npe, lat, scheduler="unipc", freeu=fu, **kw)
+        p = T.psnr(img, ref)
+        record(f"unipc_freeu_{tag}_psnr", p)
+        assert torch.isfinite(img).all() and p > bar, (tag, p)
