@@ -2,7 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffcodec_amd import ops
+from diffcodec_amd import lib, ops
+if os.environ.get("DC_LIB_PATH"):        # A/B another build of the same ABI (tools/build_dev.sh)
+    lib.LIB_PATH = os.path.abspath(os.environ["DC_LIB_PATH"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for (nq, nk, d) in [(4096, 4096, 40), (1024, 1024, 80), (256, 256, 160), (64, 64, 160), (4096, 77, 40), (1024, 77, 80)]:
     c = 8 * d
