@@ -173,6 +173,17 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
     // Staging: lane -> key (consecutive lanes, consecutive keys), wave + 4i -> 16-byte vector of the row, so "this wave has a
     // vector to move" is a scalar (wave-uniform) test and the loads run without an exec mask; keys past Nk (ragged last tile
     // only) re-read the last key: their scores are masked to -inf below and their probabilities are exactly 0.
+    // V goes to LDS in 4-row x 4-vector blocks per 16 lanes: with a row pitch of 4 or 12 (mod 16) 16-byte slots those 16 pieces fall on
+    // 16 different slots of the 256-byte bank row (lane -> row, one vector per instruction put rows r, r+4, r+8, r+12 on the SAME slot:
+    // a 4-way conflict on every V write, 18 % of the kernel's LDS cycles in the round-2/3 PMC passes), and four consecutive lanes read
+    // 64 contiguous bytes of a global row instead of one 16-byte piece each.  Staging instruction q < 4 (NV / 4): rows 16 (q & 3) +
+    // (lane >> 2), vectors 4 (q >> 2) + (lane & 3); the NV % 4 left-over vectors keep the lane -> row form.  (K: its odd pitch is
+    // conflict-free in the lane -> row form.)
+    constexpr int NVB = 4 * (NV / 4);
+    auto v_piece = [&](int q, int& row, int& vec) {           // q is wave-uniform
+        row = lane, vec = q;
+        if (NVB > 0 && q < NVB) row = 16 * (q & 3) + (lane >> 2), vec = 4 * (q >> 2) + (lane & 3);
+    };
     auto issue_loads = [&](int t) {
         const int kb = t * KV_TILE;
         int key = kb + lane;
@@ -182,7 +193,11 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             const int vec = wave + 4 * i;
             if (vec < NV) {
                 rk[i] = *(const u32x4*)(K + (long long)key * a.ks + vec * 8);
-                rv[i] = *(const u32x4*)(V + (long long)key * a.vs + vec * 8);
+                int vrow, vvec;
+                v_piece(vec, vrow, vvec);
+                int vkey = kb + vrow;
+                if (RAGGED) vkey = vkey < a.Nk ? vkey : a.Nk - 1;
+                rv[i] = *(const u32x4*)(V + (long long)vkey * a.vs + vvec * 8);
             }
         }
     };
@@ -194,7 +209,9 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             const int vec = wave + 4 * i;
             if (vec < NV) {
                 *(u32x4*)(sK + lane * K_PITCH + vec * 16) = rk[i];
-                *(u32x4*)(sV + lane * V_PITCH + vec * 16) = rv[i];
+                int vrow, vvec;
+                v_piece(vec, vrow, vvec);
+                *(u32x4*)(sV + vrow * V_PITCH + vvec * 16) = rv[i];
             }
         }
     };
@@ -436,14 +453,22 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
     if constexpr (PP) {
         const int grp = wave >> 2, w4 = wave & 3;              // group 0 stages K, group 1 stages V; w4 + 4i -> 16-byte vector of a row
         u32x4 rs[NLD];
+        auto pp_piece = [&](int q, int& row, int& vec) {       // K: lane -> row; V: the 4 x 4 blocks (see v_piece)
+            row = lane, vec = q;
+            if (NVB > 0 && grp && q < NVB) row = 16 * (q & 3) + (lane >> 2), vec = 4 * (q >> 2) + (lane & 3);
+        };
         auto pp_issue = [&](int t) {                           // this group's operand of key tile t -> registers
-            int key = t * KV_TILE + lane;
-            if (RAGGED) key = key < a.Nk ? key : a.Nk - 1;
-            const bf16_t* __restrict__ src = grp ? V + (long long)key * a.vs : K + (long long)key * a.ks;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int vec = w4 + 4 * i;
-                if (vec < NV) rs[i] = *(const u32x4*)(src + vec * 8);
+                const int q = w4 + 4 * i;
+                if (q < NV) {
+                    int row, vec;
+                    pp_piece(q, row, vec);
+                    int key = t * KV_TILE + row;
+                    if (RAGGED) key = key < a.Nk ? key : a.Nk - 1;
+                    const bf16_t* __restrict__ src = grp ? V + (long long)key * a.vs : K + (long long)key * a.ks;
+                    rs[i] = *(const u32x4*)(src + vec * 8);
+                }
             }
         };
         auto pp_store = [&](int buf) {                         // ... -> its half of LDS buffer `buf`
@@ -451,8 +476,12 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             const int pitch = grp ? V_PITCH : K_PITCH;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                const int vec = w4 + 4 * i;
-                if (vec < NV) *(u32x4*)(base + lane * pitch + vec * 16) = rs[i];
+                const int q = w4 + 4 * i;
+                if (q < NV) {
+                    int row, vec;
+                    pp_piece(q, row, vec);
+                    *(u32x4*)(base + row * pitch + vec * 16) = rs[i];
+                }
             }
         };
         // LDS buffer p & 1 holds the PAIR p = {K(p), V(p-1)}: exactly what the MFMA block of tile p reads.  Global slots: group 0
