@@ -629,7 +629,11 @@ int launch(const AttnArgs& a, hipStream_t st)
             // long context with at least one 8-wave workgroup per CU: the ping-pong form (DC_ATTN_PP=0/1: developer A/B knob)
             static const int force_pp = DC_KNOB("DC_ATTN_PP", -1);
             const long long wgs_pp = (long long)a.B * a.heads * ((a.Nq + 511) / 512);
-            if (!short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
+            // d = 16 stays on the 4-wave form: twice in round 3 an unrelated source edit produced a build whose d = 16 ping-pong kernel gave
+            // wrong rows for a few (sample, head) pairs — always wave 6, second query block, queries 16..31; register allocation was the
+            // only difference in its ISA — and the cause is not found.  Every build since passes a 17-shape x 16-launch
+            // bit-identity soak, but no SD-1.5 head is 16 wide, so the form is not worth an unexplained risk there.
+            if (D != 16 && !short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
                 if ((a.Nk % KV_TILE) != 0) return launch_qb_r<D, 2, false, true, true>(a, st);
                 return launch_qb_r<D, 2, false, false, true>(a, st);
             }

@@ -7,7 +7,7 @@ import torch
 from diffcodec_amd import lib, ops
 PKG = os.path.dirname(lib.LIB_PATH)
 so = "/tmp/libdc_cstamp.so"
-srcs = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip"]
+srcs = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip", "gemm_rowpanel.hip", "norm.hip"]
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DDC_STAMP", "-o", so] + extra +
                       [os.path.join(PKG, "csrc", s) for s in srcs])
