@@ -16,6 +16,9 @@ from .ops import PackedConv
 # +5.5 ms per 16-frame step (igemm 26 -> 14 ms against +3.5 ms gn_apply and +5.8 ms GEMM).  Module constant (tools assign it for an A/B);
 # nothing here reads the environment.
 PROJ_IN_FUSE_MIN_ROWS = 1 << 62
+# ... and the round-3 form of the same idea that does pay: where the K = 320 row-panel GEMM takes proj_in (64x64 maps, >= 65,536 rows),
+# the affine is applied to the activation panel the kernel already holds in registers — no gather GEMM, statistics epilogue kept.
+PROJ_IN_GN_ON_LOAD = True
 # LayerNorm folded into the following linear's weights + epilogue (ops.PackedConv(ln=...)): removes the three standalone
 # LayerNorm passes of every BasicTransformerBlock.  False keeps the separate dc_layernorm_bf16 launches (A/B from tools/).
 LN_FOLD = True
@@ -139,7 +142,12 @@ class TransformerBlock:
             return torch.empty((rows, parts, 2), device=x.device, dtype=torch.float32) if fold else None
 
         ab = ops.group_norm_ab(x, self.norm[0], self.norm[1], self.groups, 1e-6)
-        if n * h * w > PROJ_IN_FUSE_MIN_ROWS:                    # big maps: GroupNorm applied inside the GEMM's load stage
+        if PROJ_IN_GN_ON_LOAD and self.proj_in.bias is not None and ops.rowpanel_takes(n * h * w, h * w, c, self.proj_in.cout):
+            # 64x64 maps at decode batch sizes: the row-panel GEMM applies the GroupNorm affine to its register-resident activation panel
+            # (same arithmetic as the standalone pass): the normalized tensor is never written or re-read, the statistics epilogue stays
+            st = stats_buf(n * h * w)
+            t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False, stats_out=st).reshape(n, h * w, c)
+        elif n * h * w > PROJ_IN_FUSE_MIN_ROWS:                  # big maps: GroupNorm applied inside the GEMM's load stage
             t = ops.conv(x, self.proj_in, gn_ab=ab, gn_silu=False).reshape(n, h * w, c)
             st = ops.row_stats(t) if fold else None              # that kernel has no statistics epilogue: one read-only pass
         else:                                                    # small maps: a separate pass + the LDS-DMA GEMM is faster

@@ -92,6 +92,18 @@ __device__ __forceinline__ f32x4 dc_ln_fold(f32x4 v, float mean, float rstd, f32
     return o;
 }
 
+// GroupNorm affine of one packed bf16 pair: (x * a + b) per element as ONE fused multiply-add each, rounded to bf16 — the arithmetic of
+// dc_gn_apply_nhwc_bf16, shared with the kernels that apply the affine on load so that both give the same bits.
+// g = (a_lo, b_lo, a_hi, b_hi): the (scale, shift) pairs of two consecutive channels as dc_gn_finalize lays them out.
+__device__ __forceinline__ uint32_t dc_gn_affine_pair(uint32_t raw, f32x4 g)
+{
+#pragma clang fp contract(off)
+    const float lo = __builtin_fmaf(__uint_as_float(raw << 16), g[0], g[1]);
+    const float hi = __builtin_fmaf(__uint_as_float(raw & 0xffff0000u), g[2], g[3]);
+    const bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
+    return *(const uint32_t*)&pk;
+}
+
 // (sum, sum of squares) partials of one row -> (mean, rstd) of a LayerNorm over 1 / inv_c channels: the ONE definition behind
 // dc_ln_finalize and the consumers that finalize in their prologue (dc_conv_desc.ln_parts), so both give the same bits.
 __device__ __forceinline__ void dc_ln_mean_rstd(const float* __restrict__ row_partials, int parts, float inv_c, float eps, float& mean,

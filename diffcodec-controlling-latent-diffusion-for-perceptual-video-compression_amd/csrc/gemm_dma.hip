@@ -525,9 +525,13 @@ int launch_gemm(const dc_conv_desc& d, hipStream_t st)
 
 extern "C" int dc_gemm_row_stats_parts(int Cout) { return dc_row_stats_parts_rule(Cout); }
 
+int dc_gemm_rowpanel_wanted(const dc_conv_desc& d, int epi);
+// 1x1 launches of the LDS-DMA GEMM family.  A GroupNorm affine on load exists in the row-panel kernel only: such a launch belongs here
+// exactly when that kernel takes it (the gather GEMM of igemm.hip serves the others).
 int dc_gemm_dma_supported(const dc_conv_desc& d)
 {
-    return d.ksize == 1 && d.gn_ab == nullptr;
+    if (d.ksize != 1) return 0;
+    return d.gn_ab == nullptr || dc_gemm_rowpanel_wanted(d, epi_mode(d));
 }
 
 int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);

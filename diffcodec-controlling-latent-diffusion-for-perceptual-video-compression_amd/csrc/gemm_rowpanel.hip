@@ -108,6 +108,26 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
 #pragma unroll
         for (int k = 0; k < RP_KS; ++k) xf[tm][k] = *(const bf16x8*)(p + k * 64);
     }
+    if (d.gn_ab) {
+        // GroupNorm affine on load (dc_conv_desc.gn_ab, no SiLU: the transformer's norm in front of proj_in): the panel lies inside one
+        // sample, so every row takes the same (scale, shift) per channel; applied once to the register-resident fragments with the
+        // arithmetic of the standalone pass (dc_gn_affine_pair) — the normalized tensor is never written or re-read.
+        const long long hw = (long long)d.Ho * d.Wo;
+        const float* __restrict__ abp = d.gn_ab + ((long long)((mw / hw) % d.gn_batch) * RP_K + fq * 8) * 2;
+#pragma unroll
+        for (int k = 0; k < RP_KS; ++k) {
+            f32x4 g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = *(const f32x4*)(abp + k * 64 + 4 * j);
+#pragma unroll
+            for (int tm = 0; tm < RP_TM; ++tm) {
+                u32x4 v = *(const u32x4*)&xf[tm][k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = dc_gn_affine_pair(v[j], g[j]);
+                xf[tm][k] = *(const bf16x8*)&v;
+            }
+        }
+    }
     f32x2 ln_mr[RP_TM];
     if (e_ln) {
 #pragma unroll
@@ -362,14 +382,15 @@ int dc_gemm_rowpanel_gn_chunks(const dc_conv_desc& d)
     return hw % 256 ? 0 : (int)(hw / 32);
 }
 
-// Takes a launch when K = 320 (one source, no load-side transform), a specialised epilogue mode applies, the columns split
+// Takes a launch when K = 320 (one source; load-side transform: none, or a GroupNorm affine without SiLU), a specialised epilogue mode applies, the columns split
 // into whole 64-wide stages and the row panels fill the chip (>= one workgroup per CU).  Never depends on whether the optional
 // statistics outputs are set, so that the chunk query and the launch agree.
 // DC_GEMM_ROWPANEL (developer builds): 0 = never.
 int dc_gemm_rowpanel_wanted(const dc_conv_desc& d, int epi)
 {
     static const int mode = DC_KNOB("DC_GEMM_ROWPANEL", 1);
-    if (mode == 0 || epi < 1 || epi > 5 || d.ksize != 1 || d.gn_ab || d.splitk > 1 || d.out_f32) return 0;
+    if (mode == 0 || epi < 1 || epi > 5 || d.ksize != 1 || d.splitk > 1 || d.out_f32) return 0;
+    if (d.gn_ab && (d.gn_silu || d.gn_batch <= 0)) return 0;           // the affine on load only (the X prologue has no SiLU)
     if (d.C1 != RP_K || d.C2 != 0 || d.x2 || !d.bias) return 0;
     const long long M = (long long)d.N * d.Ho * d.Wo;
     if (M % 256 || M < 256 * 256) return 0;

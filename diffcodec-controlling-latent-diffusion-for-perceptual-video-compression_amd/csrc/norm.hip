@@ -218,12 +218,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                 uint32_t o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (!silu) {
+                        o[j] = dc_gn_affine_pair(raw[u][j], g[j]);         // (shared with the GEMM that applies the affine on load)
+                        continue;
+                    }
                     float lo = __uint_as_float(raw[u][j] << 16) * g[j][0] + g[j][1];
                     float hi = __uint_as_float(raw[u][j] & 0xffff0000u) * g[j][2] + g[j][3];
-                    if (silu) {
-                        lo = dc_silu(lo);
-                        hi = dc_silu(hi);
-                    }
+                    lo = dc_silu(lo);
+                    hi = dc_silu(hi);
                     bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
                     o[j] = *(uint32_t*)&pk;
                 }

@@ -155,6 +155,13 @@ def ln_finalize(partials, c, eps):
     return mr
 
 
+def rowpanel_takes(rows, rows_per_sample, cin, cout):
+    """Mirror of dc_gemm_rowpanel_wanted (csrc/gemm_rowpanel.hip) for plain / residual / folded-LN 1x1 launches: the K = 320 kernel that
+    keeps a 256-row panel in registers — the only GEMM of the family that can apply a GroupNorm affine on load (`gn_ab` without SiLU).
+    The C side stays the authority: a launch this rule admits and the library does not take fails with DC_ERR_INVALID."""
+    return cin == 320 and cout >= 320 and cout % 64 == 0 and rows >= 65536 and rows % 256 == 0 and rows_per_sample % 256 == 0
+
+
 def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=None, stride=1, pad=1,
          upsample=False, out_scale=1.0, out_f32=False, splitk=None, act=0, out=None, ln_stats=None, stats_out=None,
          gn_part=False, ln_partials=None):
@@ -256,7 +263,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     meta = None
     if lib.TIMER is not None:
         kk = pc.cin * k * k
-        if k == 1 and gn_ab is None:
+        if k == 1 and (gn_ab is None or (not gn_silu and x2 is None and rowpanel_takes(m, ho * wo, pc.cin, pc.cout))):
             fam = "gemm_dma_kernel + gemm_wide_kernel + gemm_rowpanel_kernel (1x1 conv / linear GEMM family)"
         elif k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample):
             fam = "conv3x3_tile_kernel (3x3 stride-1 halo-tile conv)"

@@ -182,3 +182,31 @@ def test_layernorm_finalize_folded_into_the_consumer(ops, m):
     one = ops.row_stats(t)                                                       # the single-part form (row_stats)
     pc = ops.PackedConv(torch.randn(320, K, generator=g) / math.sqrt(K), None, DEV, ln=(gamma, beta, 1e-5))
     assert torch.equal(ops.linear(t, pc, ln_stats=ops.ln_finalize(one, K, 1e-5)), ops.linear(t, pc, ln_partials=(one, 1e-5)))
+
+
+def test_groupnorm_affine_on_load_equals_the_standalone_pass(ops):
+    """dc_conv_desc.gn_ab on the row-panel GEMM (the transformer's GroupNorm in front of proj_in at 64x64): the affine is applied to the
+    register-resident activation panel with the arithmetic of dc_gn_apply_nhwc_bf16 (one shared device function), so the launch must
+    equal `conv(gn_apply(x))` bit for bit — output and row statistics — and match a float64 GroupNorm + linear."""
+    g = torch.Generator().manual_seed(31)
+    n, hw, c = 16, 64, 320
+    x = (torch.randn(n, hw, hw, c, generator=g) * 1.5 + 0.3).to(DEV, torch.bfloat16)
+    gamma, beta = (1 + 0.2 * torch.randn(c, generator=g)), 0.2 * torch.randn(c, generator=g)
+    w = bf(torch.randn(c, c, 1, 1, generator=g) / math.sqrt(c))
+    b = torch.randn(c, generator=g)
+    pc = ops.PackedConv(w, b, DEV)
+    ab = ops.group_norm_ab(x, gamma.to(DEV), beta.to(DEV), 32, 1e-6)
+    parts = ops.row_stats_parts(c)
+    st_a = torch.full((n * hw * hw, parts, 2), float("nan"), device=DEV)
+    st_b = torch.empty_like(st_a)
+    fused = ops.conv(x, pc, gn_ab=ab, gn_silu=False, stats_out=st_a)
+    two_pass = ops.conv(ops.gn_apply(x, ab), pc, stats_out=st_b)
+    assert torch.equal(fused, two_pass)
+    assert torch.equal(st_a, st_b)
+    assert torch.equal(fused, ops.conv(x, pc, gn_ab=ab, gn_silu=False))            # with or without the statistics by-product
+    xs = x[:2].double().cpu()
+    ref = F.group_norm(xs.permute(0, 3, 1, 2), 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 3, 1)
+    ref = F.linear(ref, w.double().reshape(c, c), b.double())
+    torch.testing.assert_close(fused[:2].double().cpu(), ref, rtol=2e-2, atol=4e-2)
+    with pytest.raises(Exception):                                                 # SiLU on load has no statistics epilogue anywhere
+        ops.conv(x, pc, gn_ab=ab, gn_silu=True, stats_out=st_a)
