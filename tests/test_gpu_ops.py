@@ -548,6 +548,24 @@ def test_attention_ping_pong_form(ops, b, heads, nq, nk, d):
         close(out[bi:bi + 1].float().cpu(), ref, rtol=2e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("b,heads,nq,nk,d", [(36, 8, 1024, 512, 16), (64, 8, 512, 256, 8), (16, 8, 4096, 4096, 40), (4, 8, 4096, 4096, 40),
+                                             (2, 8, 1024, 1024, 80), (32, 8, 256, 256, 160), (8, 2, 512, 512, 128),
+                                             (32, 8, 4096, 77, 40), (32, 8, 1024, 77, 80), (32, 8, 256, 77, 160)])
+def test_attention_launch_to_launch_bit_identity(ops, b, heads, nq, nk, d):
+    """Every head dim and every form of the kernel (4-wave, two query blocks per wave, 8-wave ping-pong, keys-resident short
+    context; whole and ragged key tiles): eight launches of the same inputs must be `torch.equal`, and right against SDPA.  A wrong
+    build of one instantiation showed up exactly here in round 3 ("Open")."""
+    g = torch.Generator().manual_seed(77)
+    c = heads * d
+    q, k, v = (bf(torch.randn(b, n, c, generator=g)).to(DEV, torch.bfloat16) for n in (nq, nk, nk))
+    outs = [ops.attention(q, k, v, heads) for _ in range(8)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    qh, kh, vh = (t[:2].float().view(2, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(2, nq, c)
+    close(outs[0][:2].float(), ref, rtol=2e-2, atol=1e-2)
+
+
 def test_softmax_rows(ops):
     g = torch.Generator().manual_seed(13)
     s = torch.randn(37, 4096, generator=g) * 4
