@@ -106,6 +106,12 @@ __device__ __forceinline__ uint32_t dc_gn_affine_pair(uint32_t raw, f32x4 g)
 
 // (sum, sum of squares) partials of one row -> (mean, rstd) of a LayerNorm over 1 / inv_c channels: the ONE definition behind
 // dc_ln_finalize and the consumers that finalize in their prologue (dc_conv_desc.ln_parts), so both give the same bits.
+__device__ __forceinline__ void dc_ln_mean_rstd_of_sums(float a1, float a2, float inv_c, float eps, float& mean, float& rstd)
+{
+#pragma clang fp contract(off)
+    mean = a1 * inv_c;
+    rstd = rsqrtf(fmaxf(a2 * inv_c - mean * mean, 0.f) + eps);
+}
 __device__ __forceinline__ void dc_ln_mean_rstd(const float* __restrict__ row_partials, int parts, float inv_c, float eps, float& mean,
                                                 float& rstd)
 {
@@ -116,8 +122,33 @@ __device__ __forceinline__ void dc_ln_mean_rstd(const float* __restrict__ row_pa
         a1 += v.x;
         a2 += v.y;
     }
-    mean = a1 * inv_c;
-    rstd = rsqrtf(fmaxf(a2 * inv_c - mean * mean, 0.f) + eps);
+    dc_ln_mean_rstd_of_sums(a1, a2, inv_c, eps, mean, rstd);
+}
+// The same in two phases for the row-panel GEMM's prologue (dc_conv_desc.ln_parts): the partial pairs of all of a lane's rows are FETCHED
+// first (independent loads in flight together), then SUMMED in index order as above.  (Only a kernel whose workgroup owns whole rows
+// folds the finalize: in the tile GEMMs every N tile would redo it — measured on the 256-row kernel: N = 10240, K = 1280 GEGLU 235 ->
+// 373 us — so those launches keep the standalone dc_ln_finalize pass.)
+constexpr int DC_LN_PARTS_MAX = 16;                         // = dc_row_stats_parts_rule(1280)
+struct dc_ln_row_partials {
+    float2 v[DC_LN_PARTS_MAX];
+};
+__device__ __forceinline__ void dc_ln_fetch_partials(dc_ln_row_partials& r, const float* __restrict__ row_partials, int parts)
+{
+#pragma unroll
+    for (int i = 0; i < DC_LN_PARTS_MAX; ++i)
+        if (i < parts) r.v[i] = ((const float2*)row_partials)[i];
+}
+__device__ __forceinline__ void dc_ln_mean_rstd(const dc_ln_row_partials& r, int parts, float inv_c, float eps, float& mean, float& rstd)
+{
+#pragma clang fp contract(off)
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DC_LN_PARTS_MAX; ++i)
+        if (i < parts) {
+            a1 += r.v[i].x;
+            a2 += r.v[i].y;
+        }
+    dc_ln_mean_rstd_of_sums(a1, a2, inv_c, eps, mean, rstd);
 }
 
 __device__ __forceinline__ float dc_wave_sum(float v)

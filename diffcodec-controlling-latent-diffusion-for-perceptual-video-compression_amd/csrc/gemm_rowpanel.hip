@@ -130,16 +130,19 @@ __global__ __launch_bounds__(512, 2) void gemm_rowpanel_kernel(const dc_conv_des
     }
     f32x2 ln_mr[RP_TM];
     if (e_ln) {
+        if (d.ln_parts > 0) {                                       // raw partials: the finalize pass folded into this prologue — every
+            dc_ln_row_partials rp[RP_TM];                           // row's pairs fetched first (loads in flight together), then summed
 #pragma unroll
-        for (int tm = 0; tm < RP_TM; ++tm) {
-            const long long m = mw + tm * 16 + fr;
-            if (d.ln_parts > 0) {                                   // raw partials: the finalize pass folded into this prologue
+            for (int tm = 0; tm < RP_TM; ++tm) dc_ln_fetch_partials(rp[tm], d.ln_stats + (mw + tm * 16 + fr) * d.ln_parts * 2, d.ln_parts);
+#pragma unroll
+            for (int tm = 0; tm < RP_TM; ++tm) {
                 float mean, rstd;
-                dc_ln_mean_rstd(d.ln_stats + m * d.ln_parts * 2, d.ln_parts, 1.0f / (float)RP_K, d.ln_eps, mean, rstd);
+                dc_ln_mean_rstd(rp[tm], d.ln_parts, 1.0f / (float)RP_K, d.ln_eps, mean, rstd);
                 ln_mr[tm] = f32x2{mean, rstd};
-            } else {
-                ln_mr[tm] = *(const f32x2*)(d.ln_stats + m * 2);
             }
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < RP_TM; ++tm) ln_mr[tm] = *(const f32x2*)(d.ln_stats + (mw + tm * 16 + fr) * 2);
         }
     }
 
@@ -391,6 +394,7 @@ int dc_gemm_rowpanel_wanted(const dc_conv_desc& d, int epi)
     static const int mode = DC_KNOB("DC_GEMM_ROWPANEL", 1);
     if (mode == 0 || epi < 1 || epi > 5 || d.ksize != 1 || d.splitk > 1 || d.out_f32) return 0;
     if (d.gn_ab && (d.gn_silu || d.gn_batch <= 0)) return 0;           // the affine on load only (the X prologue has no SiLU)
+    if (d.ln_parts > DC_LN_PARTS_MAX) return 0;                        // (the dispatcher finalizes first and comes back with pairs)
     if (d.C1 != RP_K || d.C2 != 0 || d.x2 || !d.bias) return 0;
     const long long M = (long long)d.N * d.Ho * d.Wo;
     if (M % 256 || M < 256 * 256) return 0;

@@ -210,3 +210,23 @@ def test_groupnorm_affine_on_load_equals_the_standalone_pass(ops):
     torch.testing.assert_close(fused[:2].double().cpu(), ref, rtol=2e-2, atol=4e-2)
     with pytest.raises(Exception):                                                 # SiLU on load has no statistics epilogue anywhere
         ops.conv(x, pc, gn_ab=ab, gn_silu=True, stats_out=st_a)
+
+
+@pytest.mark.parametrize("m,k", [(32768, 640), (8192, 1280), (2048, 1280), (512, 640), (4096, 320)])
+def test_layernorm_finalize_folded_into_the_tile_gemms(ops, m, k):
+    """dc_conv_desc.ln_parts on launches the 128-row and the 256-row ping-pong GEMMs take (every transformer level below 64x64, and
+    every level of a one-frame decode): the dispatcher runs dc_ln_finalize into the caller's scratch and proceeds on (mean, rstd)
+    pairs — the arithmetic of the explicit finalize, so it equals `ln_stats=ln_finalize(partials)` bit for bit, with 4 / 8 / 16
+    partials per row.  (Folding the finalize INTO those kernels was measured and dropped: every N tile redoes it — DESIGN.md §5.)"""
+    g = torch.Generator().manual_seed(41 + k)
+    x = _rows(g, m, k, 1.5)
+    parts = ops.row_stats_parts(k)
+    st = torch.empty((m, parts, 2), device=DEV)
+    t = ops.linear(x, ops.PackedConv(bf(torch.randn(k, k, generator=g) / math.sqrt(k)), torch.randn(k, generator=g), DEV), residual=x, stats_out=st)
+    gamma, beta = 1 + 0.2 * torch.randn(k, generator=g), 0.2 * torch.randn(k, generator=g)
+    for n_out, geglu in ((3 * k, False), (k, False), (8 * k, True)):
+        pc = ops.PackedConv(torch.randn(n_out, k, generator=g) / math.sqrt(k), 0.1 * torch.randn(n_out, generator=g), DEV,
+                            geglu=geglu, ln=(gamma, beta, 1e-5))
+        a = ops.linear(t, pc, ln_stats=ops.ln_finalize(st, k, 1e-5))
+        b = ops.linear(t, pc, ln_partials=(st, 1e-5))
+        assert torch.equal(a, b)
