@@ -372,8 +372,12 @@ extern "C" int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int
     const int C = C1 + C2;
     if (!x1 || !ab || !y || N <= 0 || HW <= 0 || (C1 & 7) || (C2 & 7) || (C2 && !x2)) return DC_ERR_INVALID;
     const int nv = C >> 3, tpp = nv < 256 ? nv : 256, ppb = 256 / tpp;
-    // >= 16 pixels per pixel-lane and workgroup (four trips of four), at most ~4096 workgroups in all
+    // >= 16 pixels per pixel-lane and workgroup (four trips of four), at most ~4096 workgroups in all — but small maps (the 8x8 and
+    // 16x16 levels: 128-512 workgroups by that rule, half the CUs idle and the launch latency-bound) go down to ONE trip of four
+    // pixels per lane until ~1024 workgroups exist
     long long chunks = HW / (16LL * ppb);
+    if (chunks < 1) chunks = 1;
+    while (chunks * N < 1024 && chunks * 2 * 4 * ppb <= HW) chunks *= 2;
     const long long cap = 4096 / N > 0 ? 4096 / N : 1;
     if (chunks > cap) chunks = cap;
     if (chunks < 1) chunks = 1;
