@@ -305,15 +305,34 @@ __global__ void splitk_finish_kernel(const dc_conv_desc d, long long total4)
     const int nb = (int)(off % d.Cout);
     const long long m = off / d.Cout;
     const int nimg = (int)(m / (d.Ho * d.Wo));
-    f32x4 v = *(const f32x4*)(d.splitk_ws + off);
-    for (int k = 1; k < d.splitk; ++k) v += *(const f32x4*)(d.splitk_ws + k * total4 * 4 + off);   // fixed order: deterministic
-    if (d.bias) v += *(const f32x4*)(d.bias + nb);
-    if (d.row_add) v += *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb);
+    // every operand is FETCHED before anything is added (left as `v += load` per split, hipcc emits load - vmcnt(0) - add per split and
+    // per epilogue operand: five to twenty dependent memory round trips in a kernel that small launches run latency-bound); the
+    // additions keep their fixed order (split 0, 1, 2, ... then bias, row_add): deterministic, and the same bits as before
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 bv = d.bias ? *(const f32x4*)(d.bias + nb) : zero;
+    const f32x4 ra = d.row_add ? *(const f32x4*)(d.row_add + (long long)nimg * d.row_add_stride + nb) : zero;
+    bf16x4 rr = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (d.residual) rr = *(const bf16x4*)((const bf16_t*)d.residual + off);
+    const float* __restrict__ slab = d.splitk_ws + off;
+    const long long ss = total4 * 4;                            // elements per split slab
+    f32x4 v = *(const f32x4*)slab;
+    int k = 1;
+    for (; k + 4 <= d.splitk; k += 4) {
+        const f32x4 a0 = *(const f32x4*)(slab + k * ss), a1 = *(const f32x4*)(slab + (k + 1) * ss);
+        const f32x4 a2 = *(const f32x4*)(slab + (k + 2) * ss), a3 = *(const f32x4*)(slab + (k + 3) * ss);
+        v += a0;
+        v += a1;
+        v += a2;
+        v += a3;
+    }
+    for (; k < d.splitk; ++k) v += *(const f32x4*)(slab + k * ss);
+    if (d.bias) v += bv;
+    if (d.row_add) v += ra;
     if (d.act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = dc_act(v[r], d.act);
     }
-    if (d.residual) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + off));
+    if (d.residual) v = dc_scale_res(v, d.out_scale, rr);
     else v *= d.out_scale;
     if (d.out_f32) {
         *(f32x4*)((float*)d.out + off) = v;
