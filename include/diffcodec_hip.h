@@ -79,7 +79,11 @@ typedef struct dc_conv_desc {
     const void* x2;         /* NHWC bf16 [N,H,W,C2] or NULL (channel concat: cat[x1,x2]) */
     const void* w;          /* bf16 [Cout][ksize*ksize][C1+C2] */
     const float* bias;      /* [Cout] or NULL */
-    const float* gn_ab;     /* [gn_batch][C1+C2][2] fp32 (scale, shift) applied on load, or NULL */
+    const float* gn_ab;     /* [gn_batch][C1+C2][2] fp32 (scale, shift) applied on load, or NULL.  1x1 launches: with gn_silu == 0 and a
+                             * shape the K = 320 row-panel GEMM takes (>= 65,536 rows, whole 256-row panels inside one sample) the affine is
+                             * applied to the kernel's register-resident activations and `stats_out` / `gn_part_out` stay available (same
+                             * bits as dc_gn_apply_nhwc_bf16 followed by the plain launch); other 1x1 launches take the gather GEMM,
+                             * which has no statistics epilogue (DC_ERR_INVALID if one is requested). */
     const float* row_add;   /* [N][Cout] fp32 added per sample (time-embedding projection) or NULL */
     const void* residual;   /* NHWC bf16 [M][Cout] added after scaling, or NULL */
     void* out;              /* bf16 [M][Cout] (f32 if out_f32; [M][Cout/2] for GEGLU) */
