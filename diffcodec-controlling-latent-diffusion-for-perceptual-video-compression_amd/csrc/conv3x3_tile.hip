@@ -726,6 +726,9 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
         static const int deep = DC_KNOB("DC_CONV_DEEP", 1);      // developer A/B knob
         const int th = v == 4 ? 8 : 4, bn = n160 ? 160 : 128;
         const long long wgs = (long long)d.N * (d.Ho / th) * (d.Wo / 16) * dc_cdiv(d.Cout, bn) * (d.splitk > 1 ? d.splitk : 1);
+        // Cout <= 32 (UNet conv_out 320 -> 4, VAE conv_out 128 -> 3 + 1): one 32-column N tile instead of a mostly empty 128-column
+        // one — a fifth of the MFMA work per pixel tile (the launch is then paced by the GroupNorm+SiLU of its halo, done once)
+        if (d.Cout <= 32) return v == 4 ? launch_tile<4, 1, 2, true>(d, st) : launch_tile<2, 1, 2, true>(d, st);
         if (deep && wgs <= 256) {
             if (v == 4) return n160 ? launch_tile<4, 5, 4, true>(d, st) : launch_tile<4, 4, 4, true>(d, st);
             return n160 ? launch_tile<2, 5, 4, true>(d, st) : launch_tile<2, 4, 4, true>(d, st);
@@ -741,6 +744,7 @@ int dc_conv3x3_tile_launch(const dc_conv_desc& d, hipStream_t st)
         if (v == 8) return n160 ? launch_tile<4, 5, 2, true, false, true>(d, st) : launch_tile<4, 4, 2, true, false, true>(d, st);
         return n160 ? launch_tile<2, 5, 2, true, false, true>(d, st) : launch_tile<2, 4, 2, true, false, true>(d, st);
     }
+    if (d.Cout <= 32 && v != 8) return v == 4 ? launch_tile<4, 1, 3>(d, st) : launch_tile<2, 1, 3>(d, st);   // (Cout = 4: not a multiple of 8)
     if (v == 4 || v == 8) return n160 ? launch_tile<4, 5, 2>(d, st) : launch_tile<4, 4, 3>(d, st);
     return n160 ? launch_tile<2, 5, 3>(d, st) : launch_tile<2, 4, 3>(d, st);
 }
