@@ -128,6 +128,20 @@ def _pick_splitk(m, cout, kt, units=None):
     return divs[-1] if divs else 1
 
 
+def _pick_splitk_strided(m, cout, kt):
+    """The stride-2 Downsample2D convs (gather GEMM, 64-row tiles): measured per shape (tools/ab/bench_down.py, model batches 32 and 2) the
+    best split is the smallest divisor of the K steps that yields ~1024 workgroups with at least 8 steps each — 1 / 2 / 4 at the three
+    levels of a 16-frame step (the general rule gave 1 / 1 / 3: 136 -> 109 us at 32x32x640), 5 at the top level of a one-frame decode
+    (53 -> 25 us), which the general rule leaves unsplit because its K loop is short."""
+    bn = 160 if cout % 160 == 0 else 128
+    tiles = math.ceil(m / 64) * math.ceil(cout / bn)
+    divs = [s for s in range(1, min(kt, 20) + 1) if kt % s == 0 and kt // s >= 8]
+    for s in divs:
+        if tiles * s >= 1024:
+            return s
+    return divs[-1] if divs else 1
+
+
 def row_stats_parts(cout):
     """Partials per row written by a 1x1 / linear launch with `stats_out` (dc_gemm_row_stats_parts)."""
     return lib.load().dc_gemm_row_stats_parts(int(cout))
@@ -227,7 +241,10 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         splitk = 1                          # the folded LayerNorm / row statistics live in the unsplit bf16 epilogue
     if splitk is None:
         tile3 = k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample)
-        splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else kt)
+        if k == 3 and stride == 2 and not pc.geglu:
+            splitk = _pick_splitk_strided(m, pc.cout, kt)
+        else:
+            splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else kt)
     ws = torch.empty((splitk, m, pc.cout), device=x1.device, dtype=F32) if splitk > 1 else None
     if gn_ab is not None:
         _chk(gn_ab, F32, "gn_ab")
