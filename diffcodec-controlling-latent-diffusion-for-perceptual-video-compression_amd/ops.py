@@ -109,19 +109,24 @@ class PackedConvF32:
 
 
 # ------------------------------------------------------------------------------------------ conv / linear
-def _pick_splitk(m, cout, kt, units=None):
+def _pick_splitk(m, cout, kt, units=None, rows_per_image=0):
     """Split the K loop over workgroups when the output has too few tiles to fill 256 CUs and K is long (the
     weight-streaming layers at 8x8 / 16x16).  Each split stores its partial tile into its own fp32 slab and a finish
     pass sums the slabs (m*cout*4 bytes written and read once per split: cheap next to the weight stream, and
     deterministic).  `units` = what the launched kernel partitions (64-channel chunks for the halo-tile 3x3 kernel,
     64-wide K steps otherwise); an even partition is preferred, so the split is a divisor of `units`."""
+    tile3 = units is not None
     units = kt if units is None else units
     bn = 160 if cout % 160 == 0 else 128
     tiles = math.ceil(m / 64) * math.ceil(cout / bn)
-    if tiles >= 512 or kt < 64:
+    # (per-shape sweep of every decode shape at model batches 32 and 2, round 3: short K loops are split only at tiny m, where nothing
+    # else fills the chip; a 1x1 launch with >= 2048 rows needs >= 128 K steps before a split pays)
+    if tiles >= 512 or (kt < 64 and (m >= 2048 or kt < 32)) or (not tile3 and m >= 2048 and kt < 128):
         return 1
     divs = [s for s in range(1, min(units, 20) + 1) if units % s == 0 and kt // s >= 8]
     target = 1024 if m >= 2048 else 256      # measured (tools/bench_splitk.py): ~1 workgroup per CU at small m, 2+ above
+    if tile3 and rows_per_image >= 1024:     # 32x32 and 64x64 maps of a one- or two-frame decode (the halo-tile kernel's own pixel tiles
+        target = 256                         # already give 64-256 workgroups): one workgroup per CU, not four (38 -> 26 us at 2x32x32x640)
     for s in divs:
         if tiles * s >= target:
             return s
@@ -244,7 +249,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         if k == 3 and stride == 2 and not pc.geglu:
             splitk = _pick_splitk_strided(m, pc.cout, kt)
         else:
-            splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else kt)
+            splitk = 1 if pc.geglu else _pick_splitk(m, pc.cout, kt, pc.cin // 64 if tile3 else None, rows_per_image=ho * wo)
     ws = torch.empty((splitk, m, pc.cout), device=x1.device, dtype=F32) if splitk > 1 else None
     if gn_ab is not None:
         _chk(gn_ab, F32, "gn_ab")
