@@ -625,6 +625,9 @@ int launch(const AttnArgs& a, hipStream_t st)
     if constexpr (D <= 48) {          // d = 80 spills at two blocks per wave (measured slower)
         const long long wgs2 = (long long)a.B * a.heads * ((a.Nq + 255) / 256);
         if (force_qb == 2 || (force_qb == 0 && wgs2 >= 512)) {
+            // short context: one query block per wave when that still fills the chip (measured at 32 x 8 x 4096 x 77, d = 40: 63 us
+            // against 70-73 us for two blocks per wave — the keys are resident either way, and the smaller workgroup tail wins)
+            if (short_ctx && force_qb == 0 && (long long)a.B * a.heads * ((a.Nq + 127) / 128) / SHORT_PASSES >= 512) return launch_qb<D, 1, true>(a, st);
             if (short_ctx && wgs2 / SHORT_PASSES >= 512) return launch_qb<D, 2, true>(a, st);
             // long context with at least one 8-wave workgroup per CU: the ping-pong form (DC_ATTN_PP=0/1: developer A/B knob)
             static const int force_pp = DC_KNOB("DC_ATTN_PP", -1);

@@ -2,7 +2,9 @@
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffcodec_amd import ops
+from diffcodec_amd import lib, ops
+if os.environ.get("DC_LIB_PATH"):        # A/B another build of the same ABI (tools/build_dev.sh)
+    lib.LIB_PATH = os.path.abspath(os.environ["DC_LIB_PATH"])
 
 DEV = "cuda"
 # (n,h,w,c1,c2,cout,k,up,gn)
