@@ -20,8 +20,11 @@
 __device__ unsigned long long dc_attn_stamp_buf[1 << 18];
 extern "C" int dc_attn_stamp_read(void* dst, int n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dc_attn_stamp_buf), (size_t)n * 8); }
 #define DC_NOW(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+#define DC_NOW_RT(t) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")   // constant 100 MHz
+#define DC_STAMP_SLOTS 16
 #else
 #define DC_NOW(t) (void)0
+#define DC_NOW_RT(t) (void)0
 #endif
 
 namespace {
@@ -60,6 +63,7 @@ struct AttnArgs {
     int B, heads, Nq, Nk;
     long long qs, ks, vs, os;
     float scale_log2e;
+    int xcd_remap;
 };
 
 // launch bound of 2 waves/SIMD (<= 256 registers) for the small heads: hipcc then emits the VGPR form of the MFMA;
@@ -111,10 +115,22 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;
+    unsigned long long st_in = 0, rt_in = 0, rt_0 = 0, rt_e = 0, st_out = 0, rt_out = 0;   // DC_STAMP: wave entry / loop / exit (cycles, 100 MHz ticks)
+    DC_NOW(st_in);
+    DC_NOW_RT(rt_in);
     constexpr int QWG = NWAVE * QW * (SHORT ? SHORT_PASSES : 1);   // queries per workgroup
     const int qblocks = (a.Nq + QWG - 1) / QWG;
-    const int bh = blockIdx.x / qblocks;
-    const int qb = blockIdx.x - bh * qblocks;
+    // XCD-aware order: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, so with the query block as the
+    // fastest index the 8 blocks of one (sample, head) at Nq = 4096 landed on 8 different XCDs and every L2 fetched every head's
+    // K/V (PMC, round 3: 4.5x the algorithmic bytes = 8 x K/V + Q + O).  Each XCD now walks a contiguous range of (head, block)
+    // pairs: the blocks of one head run on one XCD, back to back, and share its L2 copy of K/V.
+    int bid = blockIdx.x;
+    if (a.xcd_remap) {
+        const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
+    }
+    const int bh = bid / qblocks;
+    const int qb = bid - bh * qblocks;
     const int b = bh / a.heads, h = bh - b * a.heads;
     int q0 = qb * QWG + wave * QW;
 
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, s_qk = 0, s_sm = 0, s_pv = 0, s_st = 0, st_0 = 0;
     DC_NOW(st_0);
+    DC_NOW_RT(rt_0);
     f32x16 s[QB][2];                   // S^T of the current key tile (QK^T -> softmax)
     bf16x8 pf[QB][2][2];               // its probabilities as the PV MFMA's B operand (softmax -> PV)
     // ---- S^T tiles (2 x 32 keys) for every query block: each K fragment feeds QB MFMAs.  K(t) lives in LDS buffer `buf`.
@@ -326,14 +343,18 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             const float m_new = fmaxf(m_run[u], mloc);
             const float mc = m_new * a.scale_log2e;
             float lsum = 0.f;
-            const f32x2 c2 = {a.scale_log2e, a.scale_log2e}, mc2 = {mc, mc};
+            // One v_fma_f32 per score, NOT a packed v_pk_fma_f32 (this file is built with -fno-slp-vectorize so that hipcc does not
+            // re-pack them): in the peeled first tile hipcc kept (m_run * scale, mc) as ONE register pair and fed the packed FMA's
+            // addend from its HIGH register for both halves (`v_pk_fma_f32 v[4:5], s[36:37], v[34:35], v[54:55] op_sel:[0,0,1]
+            // op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]`), and on hardware the LOW half of that instruction intermittently came
+            // out as scale * s - 0 in lanes 48..63 — one probability of the tile exp2(mc) too large (round-3 "d = 16 ping-pong
+            // fragility"; DESIGN.md §5 round 4 has the ISA-level experiments).  Two scalar FMAs in its place are exact on every launch.
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const f32x2 sv = {s[u][j][r], s[u][j][r + 1]};
-                    const f32x2 tt2 = sv * c2 - mc2;                 // v_pk_fma_f32
-                    const float p0 = __builtin_amdgcn_exp2f(tt2[0]), p1 = __builtin_amdgcn_exp2f(tt2[1]);
+                    const float t0 = __builtin_fmaf(s[u][j][r], a.scale_log2e, -mc), t1 = __builtin_fmaf(s[u][j][r + 1], a.scale_log2e, -mc);
+                    const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
                     if (!ONES) lsum += p0 + p1;
                     pf[u][j][r >> 3][r & 7] = (bf16_t)p0;
                     pf[u][j][r >> 3][(r & 7) + 1] = (bf16_t)p1;
@@ -537,12 +558,21 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
         if (grp == 0) __syncthreads();                         // group 0's last barrier; group 1 is already past its last one
 #ifdef DC_STAMP
         DC_NOW(st_e);
-        if (lane == 0 && (long long)blockIdx.x * 8 + wave < (1 << 15)) {
-            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 8 + wave) * 8;
-            o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0, o[5] = 1;
-        }
+        DC_NOW_RT(rt_e);
 #endif
         store_out();
+#ifdef DC_STAMP
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // the output stores have left
+        DC_NOW(st_out);
+        DC_NOW_RT(rt_out);
+        if (lane == 0 && (long long)blockIdx.x * 8 + wave < (1 << 14)) {
+            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 8 + wave) * DC_STAMP_SLOTS;
+            o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0, o[5] = 1;
+            o[6] = st_out - st_in, o[7] = rt_e - rt_0, o[8] = rt_in, o[9] = rt_out;
+            o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4), o[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_ID, XCC_ID
+            o[12] = st_0 - st_in, o[13] = st_out - st_e;          // prologue | output
+        }
+#endif
     } else if constexpr (!SHORT) {
         for (int t = 0; t < ntiles; ++t) {
             const bool more = t + 1 < ntiles;
@@ -564,8 +594,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
 #ifdef DC_STAMP
         DC_NOW(st_e);
         if (lane == 0) {
-            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 4 + wave) * 8;
-            if ((long long)blockIdx.x * 4 + wave < (1 << 15)) o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0;
+            unsigned long long* o = dc_attn_stamp_buf + ((long long)blockIdx.x * 4 + wave) * DC_STAMP_SLOTS;
+            if ((long long)blockIdx.x * 4 + wave < (1 << 14)) o[0] = s_qk, o[1] = s_sm, o[2] = s_pv, o[3] = s_st, o[4] = st_e - st_0;
         }
 #endif
     } else {
@@ -632,11 +662,7 @@ int launch(const AttnArgs& a, hipStream_t st)
             // long context with at least one 8-wave workgroup per CU: the ping-pong form (DC_ATTN_PP=0/1: developer A/B knob)
             static const int force_pp = DC_KNOB("DC_ATTN_PP", -1);
             const long long wgs_pp = (long long)a.B * a.heads * ((a.Nq + 511) / 512);
-            // d = 16 stays on the 4-wave form: twice in round 3 an unrelated source edit produced a build whose d = 16 ping-pong kernel gave
-            // wrong rows for a few (sample, head) pairs — always wave 6, second query block, queries 16..31; register allocation was the
-            // only difference in its ISA — and the cause is not found.  Every build since passes a 17-shape x 16-launch
-            // bit-identity soak, but no SD-1.5 head is 16 wide, so the form is not worth an unexplained risk there.
-            if (D != 16 && !short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
+            if (!short_ctx && (force_pp == 1 || (force_pp < 0 && wgs_pp >= 256 && a.Nk >= 4 * KV_TILE))) {
                 if ((a.Nk % KV_TILE) != 0) return launch_qb_r<D, 2, false, true, true>(a, st);
                 return launch_qb_r<D, 2, false, false, true>(a, st);
             }
@@ -680,7 +706,7 @@ extern "C" int dc_attention_bf16(const void* q, const void* k, const void* v, vo
     if (!q || !k || !v || !out || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DC_ERR_INVALID;
     if ((q_stride | k_stride | v_stride | o_stride) & 7) return DC_ERR_INVALID;     // 16-byte aligned rows
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, B, heads, Nq, Nk,
-               q_stride, k_stride, v_stride, o_stride, scale * 1.4426950408889634f};
+               q_stride, k_stride, v_stride, o_stride, scale * 1.4426950408889634f, DC_KNOB("DC_ATTN_XCD", 1)};
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
         case 8: return launch<8>(a, st);

@@ -527,7 +527,7 @@ def test_attention_forced_rescale_and_strided_views(ops):
 
 @pytest.mark.parametrize("b,heads,nq,nk,d", [(32, 8, 4096, 4096, 40),   # the 64x64 self-attention of the decode loop at model batch 32
                                              (40, 8, 1100, 1000, 40),   # ragged: Nq not a multiple of 512, Nk not of 64
-                                             (64, 8, 512, 256, 32), (36, 8, 600, 320, 16),   # (d = 16 is kept on the 4-wave form: DESIGN.md §5, "Open")
+                                             (64, 8, 512, 256, 32), (36, 8, 600, 320, 16),   # d = 16: back on the ping-pong form since round 4 (the packed-FMA cause of its wrong rows)
                                              (32, 8, 1024, 1024, 80),    # the 32x32 self-attention at model batch 32 (4-wave form: its ping-pong variant measured no gain)
                                              (34, 8, 700, 330, 80), (40, 4, 512, 256, 64)])
 def test_attention_ping_pong_form(ops, b, heads, nq, nk, d):
