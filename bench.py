@@ -95,16 +95,18 @@ def cpu_baseline(sds, threads, device_decode=None):
 
 # PMC reference shape per kernel family (tools/pmc_conv.py launches exactly these; algorithmic bytes = inputs + weights + output)
 # value: (shape label, algorithmic bytes, launch grid in threads of that shape — what tells a family's PMC rows apart)
-PMC_SHAPES = {"gemm_": ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320; gemm_rowpanel_kernel, 512 panels x 512 threads)", 167976960, 262144),
-              "conv3x3_tile_kernel": ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360, 524288),
-              "attn_kernel": ("attention B=32 H=8 N=4096 d=40", 335544320, 1048576)}
-PMC_FILES = ("r03_pmc_summary.json", "r02_pmc_summary.json")
+# keys: (prefix the in-situ family label must START with, substring of the rocprofv3 kernel name).  The 1x1 family aggregates three
+# kernels; its PMC reference shape is a gemm_rowpanel_kernel launch, so its rows are looked up under that kernel's name.
+PMC_SHAPES = {("gemm_dma_kernel", "gemm_rowpanel_kernel"): ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320; the gemm_rowpanel_kernel launch of the gemm_dma + gemm_wide + gemm_rowpanel family, 512 panels x 512 threads)", 167976960, 262144),
+              ("conv3x3_tile_kernel", "conv3x3_tile_kernel"): ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360, 524288),
+              ("attn_kernel", "attn_kernel"): ("attention B=32 H=8 N=4096 d=40", 335544320, 1048576)}
+PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
 
 
 def latest_pmc(family):
     """HBM traffic per launch of the family's PMC reference shape, from the committed rocprofv3 --pmc passes (hardware counters
     cannot be read in-process): (2 * FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled per the gfx950 note of the guide."""
-    key = next((k for k in PMC_SHAPES if k in family), None)
+    key = next((k for k in PMC_SHAPES if family.startswith(k[0])), None)
     for name in PMC_FILES:
         p = os.path.join(ROOT, "profiles", name)
         if key is None or not os.path.exists(p):
@@ -112,7 +114,7 @@ def latest_pmc(family):
         with open(p) as fh:
             summ = json.load(fh)
         shape, alg, grid = PMC_SHAPES[key]
-        rows = [v for k, v in summ.items() if key in k and k.endswith(f"grid={grid}") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+        rows = [v for k, v in summ.items() if key[1] in k and k.endswith(f"grid={grid}") and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
         if not rows:
             continue
         r = rows[0]                                  # the launch group whose grid is the reference shape's
@@ -193,11 +195,13 @@ def main():
 
     c4 = args.config == "c4"
     pipe, sds = build_pipeline(rank, device, dual=c4)
+    bcast = None
     if world > 1:
         t0 = time.time()
         mods = [pipe.unet, pipe.vae] + (list(pipe.controlnet) if c4 else [pipe.controlnet])
         nbytes = sharding.broadcast_params(sharding.module_param_tensors(*mods))
         torch.cuda.synchronize()
+        bcast = dict(gigabytes=round(nbytes / 1e9, 3), seconds=round(time.time() - t0, 3), note="one-off weight broadcast from rank 0 in 256 MB buckets, outside the timed region")
         log(f"[rank {rank}] weight broadcast {nbytes / 1e9:.2f} GB in {time.time() - t0:.2f}s over {backend_name} (world {backend_world})")
     pipe.enable_hip_graphs(not args.no_graphs, steps_per_graph=args.steps_per_graph)
     pipe.enable_dual_stream(bool(args.dual_stream))
@@ -243,10 +247,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all() and out.shape == (F, 3, SIZE, SIZE)
+    rank_ms = None
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+        per = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per, torch.tensor([dt], device=device, dtype=torch.float64))
+        per = [p.item() for p in per]
+        dt = max(per)                                            # the contract's MAX over ranks
+        rank_ms = dict(min=round(min(per) / args.steps * 1e3, 3), max=round(max(per) / args.steps * 1e3, 3),
+                       per_rank=[round(p / args.steps * 1e3, 3) for p in per])
 
     # ---- the optional exchange, timed on its own (never part of `value`): uint8 gather of one step's units onto rank 0
     gather_ms = None
@@ -494,6 +502,7 @@ def main():
             "frame_tflop_algorithmic": None if c4 else round(TFLOP_PER_FRAME, 2),
             "frame_mfma_frac": None if c4 else round(fps / world * TFLOP_PER_FRAME / PEAK_BF16_TFLOPS, 4),
             "single_frame": single, "gop12_batch": gop12, "c3_clip_strong": c3, "gather_ms": gather_ms,
+            "rank_ms_per_step": rank_ms, "weight_broadcast": bcast,
             "unet_forward": unet_fwd, "vae_encode": vae_enc, "validation_config": validation,
             "roofline": roof, "kernel_families": families, "cpu_baseline": cpu,
         }

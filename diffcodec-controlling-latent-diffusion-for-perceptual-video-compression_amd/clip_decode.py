@@ -259,7 +259,8 @@ def decode_clip(pipe, source, num_frames, gop_size, height, width, prompt_embeds
         world = torch.distributed.get_world_size() if ini else 1
     units = plan_units(num_frames, gop_size, height, width, tile, overlap)
     mine = shard(units, rank, world, shard_mode)
-    unit_hw = (height, width) if (height, width) == (tile, tile) else (tile, tile)
+    unit_hw = (min(height, tile), min(width, tile))            # a frame smaller than the tile is one frame-sized unit (ranks with an empty
+    #                                                            share must pad their gather buffers to the SAME unit size as the others)
     images = decode_units(pipe, mine, source, prompt_embeds, negative_prompt_embeds, batch=batch, seed=seed,
                           frame_size=(height, width), unit_hw=unit_hw, **pipe_kwargs)
     u8 = units_to_u8(images)

@@ -241,7 +241,11 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
         _chk(ln_stats, F32, "ln_partials")
         assert ln_stats.dim() == 3 and ln_stats.shape[0] == m and ln_stats.shape[2] == 2
         ln_parts = int(ln_stats.shape[1])
-        ln_scratch = torch.empty((m, 2), device=x1.device, dtype=F32)     # used only when the chosen kernel cannot fold the finalize
+        # scratch for (mean, rstd): only the tile kernels need it — the row-panel kernel finalizes in its prologue (the C side mirrors
+        # `rowpanel_takes` and returns DC_ERR_INVALID if the two ever disagree)
+        takes_rp = (k == 1 and x2 is None and (gn_ab is None or not gn_silu) and pc.bias is not None and not out_f32
+                    and ln_parts <= 16 and rowpanel_takes(m, ho * wo, pc.cin, pc.cout))
+        ln_scratch = None if takes_rp else torch.empty((m, 2), device=x1.device, dtype=F32)
     if ln_stats is not None or stats_out is not None:
         splitk = 1                          # the folded LayerNorm / row statistics live in the unsplit bf16 epilogue
     if splitk is None:

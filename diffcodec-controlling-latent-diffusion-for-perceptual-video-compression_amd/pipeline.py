@@ -323,10 +323,14 @@ class StableDiffusionDualFlowControlNetPipeline:
                 mid = torch.cat([torch.zeros_like(mid), mid], 0)
             noise_pred = self.unet(x_in, t, encoder_hidden_states=text, timestep_cond=None, cross_attention_kwargs=None,
                                    down_block_additional_residuals=down, mid_block_additional_residual=mid, return_dict=False)[0]
+            unet_dtype = getattr(self.unet, "dtype", noise_pred.dtype)                  # the model dtype: what diffusers draws eta noise in
+            #                                                                             (this U-Net hands its prediction over in fp32)
             if do_cfg:                                                                  # :370-372  eps_u + g (eps_t - eps_u)
                 nu, nt_ = (t_.contiguous() for t_ in noise_pred.float().chunk(2, dim=0))
                 g32 = np.float32(guidance)                                              # 1 - g in fp32, as the fused kernels form it
                 noise_pred = ops.lincomb([(float(np.float32(1.0) - g32), nu), (float(g32), nt_)])
+            if "eta" in extra:
+                extra["noise_dtype"] = unet_dtype
             latents = self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]   # :375
             if callback is not None:                                                    # :378-381
                 loc = dict(latents=latents, prompt_embeds=pe, noise_pred=noise_pred)

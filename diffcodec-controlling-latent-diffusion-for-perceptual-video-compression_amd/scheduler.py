@@ -97,12 +97,16 @@ class DDIMScheduler:
             self.table_version = getattr(self, "table_version", 0) + 1
         return self._coef_dev
 
-    def step(self, model_output, timestep, sample, eta=0.0, generator=None, return_dict=True, **kw):
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None, return_dict=True, noise_dtype=None, **kw):
         """Generic (non-fused) entry: model_output/sample logical NCHW device tensors.
         eta > 0 (pipeline.py:289 forwards it through prepare_extra_step_kwargs) is diffusers' stochastic DDIM [recalled]:
         sigma_t = eta * sqrt((1-a_prev)/(1-a_t)) * sqrt(1 - a_t/a_prev); x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev-sigma_t^2) eps
         + sigma_t * noise, the noise drawn with the caller's generator on the generator's device (CPU generator -> CPU draw,
-        then moved: `randn_tensor`).  One `dc_lincomb4_f32` launch on fp32 state."""
+        then moved: `randn_tensor`).  One `dc_lincomb4_f32` launch on fp32 state.
+        `noise_dtype`: the dtype the variance noise is DRAWN in.  diffusers draws it in `model_output.dtype`, and in the reference the
+        CFG combine stays in the model dtype (pipeline.py:370-372), so that is the U-Net's output dtype (bf16 / fp16 at configs[1]);
+        this repo's CFG combine is fp32, so the pipeline passes the U-Net's dtype here explicitly — a CPU generator yields a different
+        stream for a bf16 draw than for an fp32 one.  Default: `model_output.dtype`.  Parity unpinned (diffusers not importable)."""
         idx = (self.timesteps == int(timestep)).nonzero()
         if idx.numel() == 0:
             raise ValueError(f"timestep {timestep} is not in the current schedule")
@@ -114,7 +118,7 @@ class DDIMScheduler:
             a_p = float(self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
             var = (1.0 - a_p) / (1.0 - a_t) * (1.0 - a_t / a_p)
             std = float(eta) * var ** 0.5
-            noise = randn_tensor(model_output.shape, generator, dev, model_output.dtype).float()   # drawn in model_output.dtype
+            noise = randn_tensor(model_output.shape, generator, dev, noise_dtype or model_output.dtype).float()
             x = sample.float().contiguous()
             eps = model_output.float().contiguous()
             c_x = (a_p / a_t) ** 0.5

@@ -136,7 +136,7 @@ class UniPCRef:
 def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flow_cond, prompt_embeds,
                  negative_prompt_embeds, latents, num_inference_steps=20, guidance_scale=7.5,
                  controlnet_conditioning_scale=1.0, output_type="pt", hoist=True, return_latents=False,
-                 control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None,
+                 control_guidance_start=0.0, control_guidance_end=1.0, eta=0.0, generator=None, noise_dtype=torch.float32,
                  res_cn_sd=None, warp_cond=None, res_conditioning_scale=None, scheduler="ddim", freeu=None):
     """pipeline.py:144-404, `prompt_embeds=` path.  hoist=True computes the step-invariant pyramid once
     (identical values to recomputing it every step as the reference does, flownet.py:78)."""
@@ -176,7 +176,9 @@ def decode_frame(unet_sd, cn_sd, vae_sd, unet_cfg, vae_cfg, controlnet_cond, flo
         if do_cfg:
             eu, et = eps.chunk(2)
             eps = eu + guidance_scale * (et - eu)                           # :370-372
-        noise = torch.randn(tuple(eps.shape), generator=generator, dtype=torch.float32) if eta else None   # :289 -> step(eta=, generator=)
+        # :289 -> step(eta=, generator=).  diffusers draws the variance noise in the model output's dtype; `noise_dtype` lets a test ask for
+        # the stream a bf16 pipeline sees (a CPU generator's bf16 draw is not its fp32 draw rounded)
+        noise = torch.randn(tuple(eps.shape), generator=generator, dtype=noise_dtype).float() if eta else None
         latents = sched.step(eps, t, latents).float() if scheduler == "unipc" else sched.step(eps, t, latents, eta, noise)   # :375
     if output_type == "latent" or return_latents and vae_sd is None:
         return latents

@@ -131,6 +131,38 @@ def test_world2_gloo_tile_sharded_clip_equals_single_rank():
     assert res[0][2] is True and res[1][3] is True          # frames exist on the gathering rank only
 
 
+def _worker_more_ranks_than_units(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, _, w = sharding.init_from_env(backend="gloo")
+    h = wd = 256
+    src = CD.SyntheticSource(h, wd, device="cpu")
+    pe = torch.zeros(1, 77, 8)
+    out = CD.decode_clip(FakePipe(), src, 3, 2, h, wd, pe, pe, tile=256, batch=2, seed=5)       # ONE inter frame = one unit for two ranks
+    ok = None
+    if r == 0:
+        ref = CD.decode_clip(FakePipe(), src, 3, 2, h, wd, pe, pe, tile=256, batch=2, seed=5, rank=0, world=1)
+        ok = sorted(out["frames"]) == [1] and np.array_equal(out["frames"][1], ref["frames"][1]) and out["frames"][1].shape == (h, wd, 3)
+    q.put((r, len(out["mine"]), tuple(out["images"].shape), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_more_ranks_than_units():
+    """a rank with an empty share pads its gather buffer to the SAME unit size as the others (frame- / tile-sized units,
+    here a 256x256 clip decoded as 256x256 units): the tensor gather neither hangs nor mis-shapes, rank 0 gets the frame."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_more_ranks_than_units, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1:] == (1, (1, 3, 256, 256), True) and res[1][1:] == (0, (0, 3, 256, 256), None)
+
+
 def test_driver_edge_cases_empty_share_and_prompt_batch():
     """a rank with no units keeps the [n,3,th,tw] shape (world > #units), the uint8 gather handles it, and a prompt batch
     that is neither 1 nor >= the chunk is refused instead of silently truncated."""

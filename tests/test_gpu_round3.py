@@ -224,7 +224,8 @@ def test_pipeline_eta_with_generator_vs_oracle(small):
     from oracle import pipeline_ref as R
     cond, flow, pe, npe, lat = _inputs(T)
     common = dict(num_inference_steps=4, guidance_scale=4.5, controlnet_conditioning_scale=1.7, eta=0.7)
-    ref = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, generator=torch.Generator().manual_seed(9), **common)
+    ref = R.decode_frame(usd, csd, vsd, T.SMALL_UNET, T.SMALL_VAE, cond, flow, pe, npe, lat, generator=torch.Generator().manual_seed(9),
+                         noise_dtype=torch.bfloat16, **common)    # the device U-Net's output dtype: what diffusers draws the eta noise in
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, output_type="pt", **common)
     img = pipe(generator=torch.Generator().manual_seed(9), **kw).images.float().cpu()
     assert T.psnr(img, ref) > 30.0
