@@ -45,6 +45,15 @@ constexpr float RESCALE_THR = 4.0f;
 #ifndef DC_ATTN_SOFTMAX_PRIO
 #define DC_ATTN_SOFTMAX_PRIO 2               // wave priority during the exp / convert block (0 = off: developer A/B)
 #endif
+#ifndef DC_ATTN_STORE_FENCE
+#define DC_ATTN_STORE_FENCE 2                // developer A/B switch: scheduling fences in front of the ping-pong form's staging stores (0 | 1 = V | 2 = V and K)
+#endif
+#ifndef DC_ATTN_QK_FIRST
+#define DC_ATTN_QK_FIRST 1                   // ping-pong form: QK^T(t) before PV(t-1) inside the MFMA block (0: the round-3 order, developer A/B)
+#endif
+#ifndef DC_ATTN_V_EARLY
+#define DC_ATTN_V_EARLY 0                    // developer A/B switch: 0 = group 1 of the ping-pong form stages V at the end of its MFMA block
+#endif
 #ifndef DC_ATTN_EARLY_STAGE
 #define DC_ATTN_EARLY_STAGE 1                // developer A/B switch: 0 = the next tile is written to LDS after the PV MFMAs
 #endif
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
     }
 
     typedef __attribute__((ext_vector_type(2))) float f32x2;
-    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, s_qk = 0, s_sm = 0, s_pv = 0, s_st = 0, st_0 = 0;
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0, s_qk = 0, s_sm = 0, s_pv = 0, s_st = 0, st_0 = 0, st_v = 0, s_vst = 0;
     DC_NOW(st_0);
     DC_NOW_RT(rt_0);
     f32x16 s[QB][2];                   // S^T of the current key tile (QK^T -> softmax)
@@ -517,11 +526,15 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
         if (grp == 1) __syncthreads();                         // group 1 runs one slot behind
         // tile 0 (peeled: no PV yet, and the softmax anchors its offset)
         if (grp == 0 && 1 < T) pp_issue(1);                    // K(1): written at the end of this tile's softmax
+        if (DC_ATTN_V_EARLY && grp == 1) {
+            pp_store(1);                                       // V(0), in registers since the prologue
+            if (DC_ATTN_V_EARLY == 1 && 1 < T) pp_issue(1);    // V(1): written at the START of the next MFMA block
+        }
         qk_part(0);
         rowmax_part(0);
-        if (grp == 1) pp_store(1);                             // V(0), in registers since the prologue
+        if (!DC_ATTN_V_EARLY && grp == 1) pp_store(1);         // V(0), in registers since the prologue
         __syncthreads();
-        if (grp == 1 && 1 < T) pp_issue(1);                    // V(1): written at the end of the next MFMA block
+        if (DC_ATTN_V_EARLY != 1 && grp == 1 && 1 < T) pp_issue(1);   // V(1)
         softmax_part(0, true);
         if (grp == 0 && 1 < T) pp_store(1);                    // K(1)
         __syncthreads();
@@ -529,20 +542,44 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             // MFMA block of tile t
             DC_NOW(st_a);
             if (grp == 0 && t + 1 < T) pp_issue(t + 1);
+            // group 1 writes V(t) (fetched during the whole previous tile) and fetches V(t+1) at the START of its MFMA block: the LDS
+            // write and its wait drain under the block's 28 MFMAs instead of standing between the row maxima and the barrier (stamps,
+            // round 4: group 1's MFMA block took 1,900 cycles against group 0's 1,490, and group 0 idled 1,360 cycles per tile at the
+            // end barrier).  Pair t+1's buffer was last read one full tile ago, so the write may come anywhere in this block.
+            if (DC_ATTN_V_EARLY && grp == 1) {
+                pp_store((t + 1) & 1);                         // V(t)
+                if (DC_ATTN_V_EARLY == 1 && t + 1 < T) pp_issue(t + 1);
+            }
+#if DC_ATTN_QK_FIRST
+            // scores first: their row maxima (a dependent v_max3 chain behind the last QK^T MFMA) then issue in the shadow of the 16 PV
+            // MFMAs instead of as a tail in front of the barrier; 236 VGPRs, no spill (round 4, same-box A/B: 950 -> 930-939 us)
+            qk_part(t & 1);
+            pv_part(t & 1);
+            rowmax_part(t);
+#else
             pv_part(t & 1);                                    // V(t-1), probabilities of tile t-1
             __builtin_amdgcn_sched_barrier(0);                 // PV before QK^T: the probabilities die before the new scores are born
             qk_part(t & 1);
             rowmax_part(t);
-            if (grp == 1) pp_store((t + 1) & 1);               // V(t)
+#endif
+            // the staging stores stay where they are written: without the fence hipcc hoists the `s_waitcnt vmcnt(0)` + ds_write of V(t)
+            // up among the block's MFMAs, where the wait stalls the matrix pipe (stamps, round 4: group 1's MFMA block 1,900 -> 1,570 cycles)
+            if (DC_ATTN_STORE_FENCE >= 1) __builtin_amdgcn_sched_barrier(0);
+#ifdef DC_STAMP
+            DC_NOW(st_v);
+#endif
+            if (!DC_ATTN_V_EARLY && grp == 1) pp_store((t + 1) & 1);               // V(t)
 #ifdef DC_STAMP
             __builtin_amdgcn_sched_barrier(0);
             DC_NOW(st_b);
+            s_vst += st_b - st_v;
 #endif
             __syncthreads();
             // softmax block of tile t
             DC_NOW(st_c);
-            if (grp == 1 && t + 1 < T) pp_issue(t + 1);
+            if (DC_ATTN_V_EARLY != 1 && grp == 1 && t + 1 < T) pp_issue(t + 1);
             softmax_part(t, false);
+            if (DC_ATTN_STORE_FENCE >= 2) __builtin_amdgcn_sched_barrier(0);   // K(t+1) is written AFTER the exponentials (hipcc puts its vmcnt(0) in front of them)
             if (grp == 0 && t + 1 < T) pp_store((t + 1) & 1);  // K(t+1)
 #ifdef DC_STAMP
             __builtin_amdgcn_sched_barrier(0);
@@ -571,6 +608,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             o[6] = st_out - st_in, o[7] = rt_e - rt_0, o[8] = rt_in, o[9] = rt_out;
             o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4), o[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_ID, XCC_ID
             o[12] = st_0 - st_in, o[13] = st_out - st_e;          // prologue | output
+            o[14] = s_vst;                                        // group 1: V(t) wait + LDS write at the end of the MFMA block
         }
 #endif
     } else if constexpr (!SHORT) {

@@ -75,7 +75,7 @@ __device__ __forceinline__ void wait_vmcnt()
 // SH (FAST only, no fused GroupNorm): 8-wide maps — an MFMA row group covers two image rows of 8 pixels (and, with 8-row tiles, a
 // tile covers two whole 8x8 images); only the per-lane base address and the immediates differ.  Direct (unstaged) stores.
 template <int TM, int TN, bool GN, int NSTB, int EPI, bool FAST, bool UPS = false, bool SH = false>
-__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d)
+__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc d, const int m_fastest)
 {
     static_assert(!SH || (FAST && !GN && !UPS), "the narrow-map form exists on the pipelined path, without GroupNorm on load");
     static_assert(!FAST || NSTB == 2 || NSTB == 4, "the half-step pipeline indexes its weight ring with step & (NSTB - 1)");
@@ -121,8 +121,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
         const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
     }
-    const int tile_n = bid % n_tiles;
-    int tile_m = bid / n_tiles;
+    // Which index runs fastest inside an XCD's contiguous range decides what its L2 shares: n fastest (the default) keeps one pixel
+    // tile's halo resident while its N tiles stream the weights; m fastest keeps one WEIGHT tile resident while the pixel tiles walk
+    // past it — the right order where the weights are the bigger operand (the 8x8 / 16x16 levels: 29.5 MB of weights against 5-21 MB
+    // of activations; with n fastest every XCD streamed all of them, 8 x 29.5 MB per launch).  The launcher decides (`tile_order`).
+    const int tile_n = m_fastest ? bid / m_tiles : bid % n_tiles;
+    int tile_m = m_fastest ? bid - tile_n * m_tiles : bid / n_tiles;
     const int n_img0 = dual ? 2 * tile_m : tile_m / (tiles_y * tiles_x);
     tile_m = dual ? 0 : tile_m - n_img0 * tiles_y * tiles_x;
     const int n_img = dual ? n_img0 + wm : n_img0;              // image of this wave's output rows
@@ -646,12 +650,15 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
     const size_t lds = HALO_ROWS * (FAST ? 160 : 128) + NSTB * BN * 128;
 #endif
     const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
+    // tile order inside an XCD's range (see the kernel): pixel tiles fastest when the weight tensor is larger than the activations
+    static const int force_order = DC_KNOB("DC_CONV_ORDER", -1);   // developer A/B knob: 0 = n fastest, 1 = m fastest
+    const int order = force_order >= 0 ? force_order : ((long long)d.Cout * 9 > (long long)d.N * d.H * d.W ? 1 : 0);
 #define DC_TILE_LAUNCH1(GN, EPI)                                                                                \
     do {                                                                                                        \
         auto kern = conv3x3_tile_kernel<TM, TN, GN, NSTB, EPI, FAST, (UPS && !GN), (SH && !GN)>;                                                    \
         static std::atomic<unsigned long long> attr_done{0};                                                    \
         dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);                                             \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d);                                                  \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, order);                                           \
     } while (0)
 #define DC_TILE_LAUNCH(GN)                          \
     do {                                            \

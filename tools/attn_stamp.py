@@ -55,6 +55,12 @@ if pp:
     print("  (ping-pong form: the four columns are MFMA block {PV(t-1), QK^T(t)} | barrier wait | softmax block | barrier wait)")
 print("MFMA floor per tile and wave: QK^T 12 x 32 = 384, PV 16 x 32 = 512;  tile loop %.0f cycles per wave" % m(4))
 if pp:
+    wv = t.view(-1, 8, SLOTS)
+    for g, name in ((slice(0, 4), "group 0 (waves 0-3, stage K)"), (slice(4, 8), "group 1 (waves 4-7, stage V)")):
+        x = wv[:, g].reshape(-1, SLOTS)
+        mm = lambda c: x[:, c].mean().item() / (tiles - 1)
+        print("  %s: mean cycles per tile: MFMA block %.0f (of it V wait + write %.0f) | wait at mid barrier %.0f | softmax block %.0f | wait at end barrier %.0f | sum %.0f" %
+              (name, mm(0), mm(14), mm(1), mm(2), mm(3), mm(0) + mm(1) + mm(2) + mm(3)))
     clk = (t[:, 4] / t[:, 7]).median().item() * 0.1          # cycles per 10 ns tick -> GHz
     print("in-kernel clock of the tile loop (delta s_memtime / delta s_memrealtime): %.3f GHz (median over waves; min %.3f max %.3f)" %
           (clk, (t[:, 4] / t[:, 7]).min().item() * 0.1, (t[:, 4] / t[:, 7]).max().item() * 0.1))
