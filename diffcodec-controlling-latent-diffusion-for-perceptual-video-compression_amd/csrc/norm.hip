@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void gn_direct_kernel(const bf16_t* __restrict
 // y = (x*a+b) [SiLU] of cat[x1,x2].  grid = (pixel chunks, N); a thread owns one 8-channel vector column of one sample (its
 // 16 scale/shift floats stay in registers) and walks the chunk's pixels four at a time, so four 16-byte loads are in flight
 // per thread and the only per-pixel work is the arithmetic: no index divisions, no re-reads of the affine.
+template <int UNR, bool NT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x1, int C1,
                                                        const bf16_t* __restrict__ x2, int C2,
                                                        const float* __restrict__ ab, bf16_t* __restrict__ y,
@@ -204,15 +205,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         const bf16_t* src = first ? x1 + (long long)n * HW * C1 + c : x2 + (long long)n * HW * C2 + (c - C1);
         const int cs = first ? C1 : C2;
         bf16_t* dst = y + (long long)n * HW * C + c;
-        for (long long p0 = p_begin + pl; p0 < p_end; p0 += 4LL * ppb) {
-            u32x4 raw[4];
+        for (long long p0 = p_begin + pl; p0 < p_end; p0 += (long long)UNR * ppb) {
+            u32x4 raw[UNR];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const long long p = p0 + (long long)u * ppb;
                 if (p < p_end) raw[u] = *(const u32x4*)(src + p * cs);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const long long p = p0 + (long long)u * ppb;
                 if (p >= p_end) break;
                 uint32_t o[4];
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                     bf16x2 pk = {(bf16_t)lo, (bf16_t)hi};
                     o[j] = *(uint32_t*)&pk;
                 }
-                *(u32x4*)(dst + p * C) = u32x4{o[0], o[1], o[2], o[3]};
+                const u32x4 ov = {o[0], o[1], o[2], o[3]};
+                if (NT) __builtin_nontemporal_store(ov, (u32x4*)(dst + p * C));
+                else *(u32x4*)(dst + p * C) = ov;
             }
         }
     }
@@ -382,8 +385,14 @@ extern "C" int dc_gn_apply_nhwc_bf16(const void* x1, int C1, const void* x2, int
     if (chunks > cap) chunks = cap;
     if (chunks < 1) chunks = 1;
     const int pix_per_block = (int)((HW + chunks - 1) / chunks);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)dc_cdiv(HW, pix_per_block), N), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x1, C1, (const bf16_t*)x2, C2, ab, (bf16_t*)y, HW, pix_per_block, silu);
+    static const int unr = DC_KNOB("DC_GN_UNR", 4), nt = DC_KNOB("DC_GN_NT", 0);     // developer A/B knobs
+    const dim3 grid((unsigned)dc_cdiv(HW, pix_per_block), N);
+#define DC_GN_APPLY(U, T) hipLaunchKernelGGL((gn_apply_kernel<U, T>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x1, C1, \
+                                             (const bf16_t*)x2, C2, ab, (bf16_t*)y, HW, pix_per_block, silu)
+    if (unr == 8) { if (nt) DC_GN_APPLY(8, true); else DC_GN_APPLY(8, false); }
+    else if (unr == 2) { if (nt) DC_GN_APPLY(2, true); else DC_GN_APPLY(2, false); }
+    else { if (nt) DC_GN_APPLY(4, true); else DC_GN_APPLY(4, false); }
+#undef DC_GN_APPLY
     return dc_launch_status();
 }
 

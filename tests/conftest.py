@@ -17,6 +17,15 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+def record_value(name, value):
+    """Module-level form of the `record` fixture (for tests that do not take fixtures by name)."""
+    path = os.environ.get("DC_TEST_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(f"{name}\t{value}\n")
+    return value
+
+
 @pytest.fixture(scope="session")
 def record():
     """record(name, value): append a measured value (PSNR, rel-L2 ...) to the file named by $DC_TEST_LOG, so that the bars in

@@ -11,6 +11,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import record_value
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -228,7 +229,7 @@ def test_pipeline_eta_with_generator_vs_oracle(small):
                          noise_dtype=torch.bfloat16, **common)    # the device U-Net's output dtype: what diffusers draws the eta noise in
     kw = dict(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, output_type="pt", **common)
     img = pipe(generator=torch.Generator().manual_seed(9), **kw).images.float().cpu()
-    assert T.psnr(img, ref) > 30.0
+    assert record_value("test_gpu_round3_L231", T.psnr(img, ref)) > 40.0               # measured 43.5 dB (round 4)
     other = pipe(generator=torch.Generator().manual_seed(10), **kw).images.float().cpu()
     det = pipe(**dict(kw, eta=0.0)).images.float().cpu()
     assert T.psnr(other, img) < 40.0 and T.psnr(det, img) < 40.0           # the noise is really injected, and seeded
@@ -332,7 +333,7 @@ def test_checkpoint_seam_synthetic_diffusers_directory(small, tmp_path):
     img = pipe(prompt_embeds=pe, negative_prompt_embeds=npe, controlnet_cond=cond, flow_cond=flow, latents=lat, output_type="pt", **kw).images.float().cpu()
     f32 = lambda sd: {k: v.float() for k, v in sd.items()}
     ref = R.decode_frame(f32(usd_l), f32(ckpt), f32(vsd_l), ucfg_l, vcfg_l, cond, flow, pe, npe, lat, **kw)
-    assert T.psnr(img, ref) > 30.0
+    assert record_value("test_gpu_round3_L335", T.psnr(img, ref)) > 39.5               # measured 42.5 dB (round 4)
     orig = R.decode_frame(usd, csd, vsd, ucfg, vcfg, cond, flow, pe, npe, lat, **kw)
     assert T.psnr(ref, orig) < 60.0                      # the replaced metric_net / zero-conv tensors do change the model
 
