@@ -260,6 +260,10 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
     f32x16 s[QB][2];                   // S^T of the current key tile (QK^T -> softmax)
     bf16x8 pf[QB][2][2];               // its probabilities as the PV MFMA's B operand (softmax -> PV)
     // ---- S^T tiles (2 x 32 keys) for every query block: each K fragment feeds QB MFMAs.  K(t) lives in LDS buffer `buf`.
+    // 32-key halves of the current key tile that hold at least one real key: 2, or 1 in the short-context form's last tile when the
+    // context ends inside its first half (the 77-token text context: keys 64..76 of tile 1 -> its second half is all padding; skipping
+    // it removes a quarter of every cross-attention's MFMA and softmax work).  Wave-uniform; a constant 2 in the long-context forms.
+    int jn = 2;
     auto qk_part = [&](int buf) {
         const char* sK = smem + buf * BUF;
 #pragma unroll
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < ND16; ++ks) {
+                if (j >= jn) continue;
                 const bf16x8 kf = *(const bf16x8*)(sK + (32 * j + lq) * K_PITCH + (16 * ks + 8 * lh) * 2);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u][j], 0, 0, 0);
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
+                        if (j >= jn) continue;
                         const int key = kb + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         if (key >= a.Nk) s[u][j][r] = -INFINITY;
                     }
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[u][j][r]);
+                for (int r = 0; r < 16; ++r)
+                    if (j < jn) mloc = fmaxf(mloc, s[u][j][r]);
             {   // exchange with lane ^ 32 on the VALU (v_permlane32_swap) instead of an LDS round trip (ds_bpermute)
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
                 mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
+                    if (j >= jn) continue;
                     const float t0 = __builtin_fmaf(s[u][j][r], a.scale_log2e, -mc), t1 = __builtin_fmaf(s[u][j][r + 1], a.scale_log2e, -mc);
                     const float p0 = __builtin_amdgcn_exp2f(t0), p1 = __builtin_amdgcn_exp2f(t1);
                     if (!ONES) lsum += p0 + p1;
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    if (j >= jn) continue;
                     const char* pk = vbase + (32 * j + 16 * s2) * V_PITCH + tt * 64;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)pk);
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(pk + 8 * V_PITCH));
@@ -646,7 +655,12 @@ __global__ __launch_bounds__(PP ? 512 : 256, (D <= 80 ? 2 : 1)) void attn_kernel
             const bool has_next = pass + 1 < SHORT_PASSES && q0 + 4 * QW < a.Nq;
             bf16x8 qn[QB][ND16];
             if (has_next) fetch_q(q0 + 4 * QW, qn);            // next block's queries fly while this one computes
-            for (int t = 0; t < ntiles; ++t) process_tile(t, t == 0, false);
+            // (round 4, measured and NOT adopted: query blocks prefetched TWO passes ahead — 61 -> 64.5 us at 32 x 8 x 4096 x 77; and the skipped
+            //  dead half below removes a quarter of the form's MFMA / softmax work without moving its time: the form is bound by neither)
+            for (int t = 0; t < ntiles; ++t) {
+                jn = (t * KV_TILE + 32 >= a.Nk) ? 1 : 2;       // (RAGGED is always on in this form)
+                process_tile(t, t == 0, false);
+            }
             store_out();
             if (!has_next) break;
             q0 += 4 * QW;
