@@ -27,7 +27,7 @@ for (hw, cin, cout, kind) in SHAPES:
     pc = ops.PackedConv(w, torch.zeros(cout), DEV, geglu="g" in kind, ln=ln)
     oc = cout // 2 if "g" in kind else cout
     res = torch.randn(1, m, cout, generator=g).to(DEV, torch.bfloat16) if kind == "r" else None
-    st = torch.empty((m, ops.row_stats_parts(cout), 2), device=DEV) if kind == "r" else None
+    st = torch.empty((m, ops.row_stats_parts(cout), 2), device=DEV) if kind == "r" and not os.environ.get("DC_BENCH_NOSTATS") else None
     mr = ops.ln_finalize(ops.row_stats(x), cin, 1e-5) if ln is not None else None
     f = lambda: ops.linear(x, pc, residual=res, stats_out=st, ln_stats=mr)
     for _ in range(3):
