@@ -5,7 +5,7 @@ import torch
 from diffcodec_amd import ops
 g = torch.Generator().manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for (h, c, cout, k) in [(64, 320, 320, 3), (32, 640, 640, 3), (64, 320, 320, 1)]:
+for (h, c, cout, k) in [(64, 320, 320, 3), (32, 640, 640, 3), (64, 320, 320, 1), (16, 1280, 1280, 3), (8, 1280, 1280, 3)]:
     x = torch.randn(n, h, h, c, generator=g).to("cuda", torch.bfloat16)
     pc = ops.PackedConv(torch.randn(cout, c, k, k, generator=g) / math.sqrt(c * k * k), torch.zeros(cout), "cuda")
     for _ in range(5):
@@ -28,6 +28,17 @@ for _ in range(3):
     o = ops.attention(q[..., :320], q[..., 320:640], q[..., 640:], 8)
 torch.cuda.synchronize()
 print(f"shape attention B={n} H=8 N=4096 d=40: algorithmic bytes = {q.numel()*2 + o.numel()*2}")
+# the 32x32 self-attention (d = 80) and the 64x64 text cross-attention (77 keys, d = 40)
+q8 = torch.randn(n, 1024, 1920, generator=g).to("cuda", torch.bfloat16)
+for _ in range(3):
+    o8 = ops.attention(q8[..., :640], q8[..., 640:1280], q8[..., 1280:], 8)
+kv = torch.randn(n, 77, 640, generator=g).to("cuda", torch.bfloat16)
+qs = torch.randn(n, 4096, 320, generator=g).to("cuda", torch.bfloat16)
+for _ in range(3):
+    os_ = ops.attention(qs, kv[..., :320], kv[..., 320:], 8)
+torch.cuda.synchronize()
+print(f"shape attention B={n} H=8 N=1024 d=80: algorithmic bytes = {q8.numel()*2 + o8.numel()*2}")
+print(f"shape attention B={n} H=8 Nq=4096 Nk=77 d=40: algorithmic bytes = {qs.numel()*2 + kv.numel()*2 + os_.numel()*2}")
 # GroupNorm apply (+SiLU) and statistics, 64x64x640: the HBM-bound passes
 xg = torch.randn(n, 64, 64, 640, generator=g).to("cuda", torch.bfloat16)
 ab = torch.randn(n, 640, 2, generator=g).to("cuda")
