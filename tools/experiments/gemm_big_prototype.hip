@@ -199,8 +199,13 @@ __global__ __launch_bounds__(256, 1) void gemm_big_kernel(const dc_conv_desc d, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA piece may be in flight when the workgroup's LDS is released
 
-    // ---- epilogue (prototype: 8-byte stores straight from the MFMA layout: lane (fr, fq) of tile (tn, tm) holds row tm*16 + fr,
-    //      columns tn*16 + 4 fq .. + 3)
+    // ---- epilogue: the tile is staged through LDS (the ring is free: every DMA has landed, every fragment read has returned, and the
+    //      barrier below separates the last slice's reads from the first staged row) and written as whole 16-byte pieces of contiguous
+    //      output rows; lane (fr, fq) of tile (tn, tm) holds row tm*16 + fr, columns tn*16 + 4 fq .. + 3.  Same expressions and the same
+    //      staging swizzle as gemm_wide.hip.
+    constexpr int OC = e_geglu ? BN / 2 : BN;
+    constexpr int PITCH = OC * 2 + 16;
+    static_assert(BM * PITCH <= NST * STAGE, "output tile must fit in the ring");
     const int out_cols = e_geglu ? d.Cout >> 1 : d.Cout;
     bf16_t* __restrict__ o = (bf16_t*)d.out;
     f32x4 bv[TN], cs[TN];
@@ -210,9 +215,12 @@ __global__ __launch_bounds__(256, 1) void gemm_big_kernel(const dc_conv_desc d, 
         bv[tn] = *(const f32x4*)(d.bias + nb);
         cs[tn] = e_ln ? *(const f32x4*)(d.ln_colsum + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + wm * 128 + tm * 16 + fr;
+        const int row = wm * 128 + tm * 16 + fr;
+        const int m = m0 + row;
         f32x2 mr = {0.f, 1.f};
         if (e_ln) mr = *(const f32x2*)(d.ln_stats + (long long)m * 2);
         if (e_geglu) {
@@ -228,23 +236,30 @@ __global__ __launch_bounds__(256, 1) void gemm_big_kernel(const dc_conv_desc d, 
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(h[r] * dc_gelu_erf(g[r]));
-                *(bf16x4*)(o + (long long)m * out_cols + ((n0 + wn * 128 + (2 * tp) * 16) >> 1) + 4 * fq) = pk;
+                *(bf16x4*)(smem + row * PITCH + (((((wn * 128 + 2 * tp * 16) >> 1) + 4 * fq) * 2) ^ dc_stage_swz(row))) = pk;
             }
         } else {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
-                const int nb = n0 + wn * 128 + tn * 16 + 4 * fq;
+                const int nl = wn * 128 + tn * 16 + 4 * fq;
                 f32x4 v = acc[tn][tm];
                 if (e_ln) v = dc_ln_fold(v, mr[0], mr[1], cs[tn]);
                 v += bv[tn];
-                if (e_res) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + (long long)m * d.Cout + nb));
+                if (e_res) v = dc_scale_res(v, d.out_scale, *(const bf16x4*)((const bf16_t*)d.residual + (long long)m * d.Cout + n0 + nl));
                 else v *= d.out_scale;
                 bf16x4 pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
-                *(bf16x4*)(o + (long long)m * d.Cout + nb) = pk;
+                *(bf16x4*)(smem + row * PITCH + ((nl * 2) ^ dc_stage_swz(row))) = pk;
             }
         }
+    }
+    __syncthreads();
+    const int col0 = e_geglu ? n0 >> 1 : n0;
+    constexpr int pieces = OC / 8;                    // 16-byte pieces per staged row
+    for (int i = tid; i < BM * pieces; i += 256) {
+        const int row = i / pieces, pc = i - row * pieces;
+        *(u32x4*)(o + (long long)(m0 + row) * out_cols + col0 + pc * 8) = dc_stage_unswz(*(const u32x4*)(smem + row * PITCH + pc * 16), row);
     }
 }
 
