@@ -28,6 +28,9 @@
 #ifndef DC_CONV_FAST
 #define DC_CONV_FAST 1          // developer A/B switch: 0 = plain maps also take the XOR-swizzled, whole-step K loop
 #endif
+#ifndef DC_SH_HP
+#define DC_SH_HP 160            // halo pixel pitch of the narrow-map (8-wide) pipelined form (developer A/B: 144 / 176 / 192)
+#endif
 #ifndef DC_CONV_PIPE
 #define DC_CONV_PIPE 1          // developer A/B switch for the scheduled K-step (see `mfma_frags`)
 #endif
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const dc_conv_desc
     constexpr int HALO_MAX = UPS ? (TH / 2 + 2) * 10 : SH ? (TM == 4 ? 200 : ((TH << 1) + 2) * 10) : ((TM == 4 && !FAST) ? 200 : (TH + 2) * 18);   // TM == 4 also serves two stacked 8x8 images (2 x 10 x 10)
     constexpr int NHU = (HALO_MAX * 8 + 255) / 256;   // 16-byte halo units per thread
     constexpr int NB = BN / 32;                       // weight-tile DMA wave-instructions per wave per stage
-    constexpr int HP = FAST ? 160 : 128;              // halo pixel-row pitch (bytes)
+    constexpr int HP = FAST ? (SH ? DC_SH_HP : 160) : 128;   // halo pixel-row pitch (bytes)
     constexpr int H_BYTES = HALO_MAX * HP;
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -647,7 +650,7 @@ int launch_tile(const dc_conv_desc& d, hipStream_t st)
 #ifdef DC_EXP_ONE_WG            // developer experiment: pad the allocation so one workgroup owns the CU
     const size_t lds = 96 * 1024;
 #else
-    const size_t lds = HALO_ROWS * (FAST ? 160 : 128) + NSTB * BN * 128;
+    const size_t lds = HALO_ROWS * (FAST ? (SH ? DC_SH_HP : 160) : 128) + NSTB * BN * 128;
 #endif
     const int epi = (!DC_EPI_SPECIALIZE || d.splitk > 1 || d.out_f32 || d.act) ? 0 : (d.residual ? 2 : 1);
     // tile order inside an XCD's range (see the kernel): pixel tiles fastest when the weight tensor is larger than the activations

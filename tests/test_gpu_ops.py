@@ -208,6 +208,11 @@ CONV_CASES = [
     (10, 64, 64, 128, 64, 320, 3, 1, 1, False),     # the same path with > 256 workgroups: two-slot ring, two workgroups per CU, skip concat
     (9, 32, 16, 192, 0, 256, 3, 1, 1, False),       # 128-column tiles, 4-row tiles, batch not a power of two
     (2, 8, 8, 1280, 1280, 1280, 3, 1, 1, False),    # UNet 8x8 up-block conv (split-K path)
+    # weight-stationary tile order (round 4: pixel tile fastest inside an XCD where Cout * 9 > N * H * W) on grids that are not a multiple of 8
+    (3, 8, 8, 640, 0, 1280, 3, 1, 1, False),        # 8x8, odd batch: 4-row tiles, 3 x 8 N tiles
+    (6, 8, 8, 320, 0, 1280, 3, 1, 1, False),        # 8x8, two images per tile
+    (5, 16, 16, 320, 0, 1280, 3, 1, 1, False),      # 16x16: 5 x 2 pixel tiles x 8 N tiles
+    (1, 16, 16, 256, 0, 640, 3, 1, 1, True),        # fused upsample (16x16 -> 32x32) in the new order
 ]
 
 
@@ -496,7 +501,10 @@ def test_wide_gemm_long_k_shapes(ops, m, k, n):
                                              (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),
                                              (1, 2, 33, 5, 8), (1, 3, 200, 200, 32), (1, 1, 128, 192, 128),
                                              # text cross-attention at full batch: keys resident, 4 query blocks per workgroup
-                                             (16, 8, 4096, 77, 40), (32, 8, 1000, 77, 80), (40, 8, 250, 100, 160)])
+                                             (16, 8, 4096, 77, 40), (32, 8, 1000, 77, 80), (40, 8, 250, 100, 160),
+                                             # grids that are NOT a multiple of 8 workgroups (the XCD-aware block order of round 4 has to stay a
+                                             # bijection there): 3 x 5 heads, ragged query counts; long, ping-pong and short-context forms
+                                             (3, 5, 700, 300, 40), (3, 5, 700, 77, 40), (37, 7, 1500, 320, 40), (5, 3, 130, 70, 80), (67, 7, 2100, 77, 40)])
 def test_attention(ops, b, heads, nq, nk, d):
     g = torch.Generator().manual_seed(11)
     c = heads * d
