@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdiffcodec_hip.so")
-SOURCES = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip", "gemm_rowpanel.hip", "attention.hip", "norm.hip", "splat.hip", "conv_direct.hip", "conv_f32_mfma.hip", "elementwise.hip", "text.hip"]
+SOURCES = ["igemm.hip", "conv3x3_tile.hip", "gemm_dma.hip", "gemm_wide.hip", "gemm_p8.hip", "gemm_rowpanel.hip", "attention.hip", "norm.hip", "splat.hip", "conv_direct.hip", "conv_f32_mfma.hip", "elementwise.hip", "text.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 # per-file flags: attention.hip keeps its softmax arithmetic as single v_fma_f32 / v_mul_f32 (no compiler-formed v_pk_*_f32 with
 # cross-half op_sel operands: the cause of the round-3 d = 16 wrong rows)

@@ -539,6 +539,9 @@ int dc_gemm_dma_gn_chunks(const dc_conv_desc& d);
 int dc_gemm_wide_wanted(const dc_conv_desc& d, int epi);
 int dc_gemm_wide_launch(const dc_conv_desc& d, int epi, hipStream_t st);
 int dc_gemm_wide_gn_chunks(const dc_conv_desc& d);
+// gemm_p8.hip: the 256 x 256 four-phase kernel for the long-K, wide-N linears without residual / statistics
+int dc_gemm_p8_wanted(const dc_conv_desc& d, int epi);
+int dc_gemm_p8_launch(const dc_conv_desc& d, int epi, hipStream_t st);
 // gemm_rowpanel.hip: the K = 320 kernel that keeps a 256-row activation panel in registers and streams only W
 int dc_gemm_rowpanel_wanted(const dc_conv_desc& d, int epi);
 int dc_gemm_rowpanel_launch(const dc_conv_desc& d, int epi, hipStream_t st);
@@ -564,6 +567,8 @@ int dc_gemm_dma_launch(const dc_conv_desc& d, hipStream_t st)
             q.ln_parts = 0;
             return dc_gemm_dma_launch(q, st);
         }
+        if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;
+        if (dc_gemm_p8_wanted(d, epi)) return dc_gemm_p8_launch(d, epi, st);
         if (dc_gemm_wide_wanted(d, epi)) return dc_gemm_wide_launch(d, epi, st);
     }
     if (d.ln_stats && !d.ln_colsum) return DC_ERR_INVALID;

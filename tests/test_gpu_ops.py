@@ -496,6 +496,36 @@ def test_wide_gemm_long_k_shapes(ops, m, k, n):
     close(ops.conv(xa, pc, x2=xb).reshape(1, m, n).float().cpu(), ref)
 
 
+@pytest.mark.parametrize("m,k,n", [(8192, 640, 3584), (7168, 1344, 4096)])
+def test_p8_gemm_shapes(ops, m, k, n):
+    """Shapes the dispatcher hands to the 256 x 256 four-phase GEMM (gemm_p8.hip: no residual / statistics, whole 256 x 256 tiles,
+    >= 448 of them, K >= 640; an even and an odd number of K tiles): bias, folded LayerNorm, GEGLU, folded LayerNorm + GEGLU against
+    fp32 torch on the same bf16 operands.  Each launch twice (the DMA / barrier protocol must give the same bits), and the first 256
+    rows against a 256-row launch of the same operator, which another kernel of the family takes: the kernels accumulate in the
+    same order with the same epilogue arithmetic, so the bits must agree."""
+    g = torch.Generator().manual_seed(41)
+    x = bf(torch.randn(1, m, k, generator=g))
+    w = bf(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g) * 0.1
+    xd = x.to(DEV, torch.bfloat16)
+    head = xd[:, :256].contiguous()
+    lg, lb = 1 + 0.2 * torch.randn(k, generator=g), 0.2 * torch.randn(k, generator=g)
+    ln = F.layer_norm(x, (k,), lg, lb, 1e-5)
+    mr = ops.ln_finalize(ops.row_stats(xd), k, 1e-5)
+    mr_head = mr[:256].contiguous()
+    hid, gate = F.linear(x, w, b).chunk(2, -1)
+    hid_ln, gate_ln = F.linear(ln, w, b).chunk(2, -1)
+    cases = [(ops.PackedConv(w, b, DEV), None, F.linear(x, w, b)),
+             (ops.PackedConv(w, b, DEV, ln=(lg, lb, 1e-5)), mr, F.linear(ln, w, b)),
+             (ops.PackedConv(w, b, DEV, geglu=True), None, hid * F.gelu(gate)),
+             (ops.PackedConv(w, b, DEV, geglu=True, ln=(lg, lb, 1e-5)), mr, hid_ln * F.gelu(gate_ln))]
+    for pc, stats, ref in cases:
+        out = ops.linear(xd, pc, ln_stats=stats)
+        close(out.float().cpu(), ref, rtol=3e-2, atol=3e-2)
+        assert torch.equal(out, ops.linear(xd, pc, ln_stats=stats))
+        assert torch.equal(out[:, :256], ops.linear(head, pc, ln_stats=None if stats is None else mr_head))
+
+
 # ------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("b,heads,nq,nk,d", [(2, 8, 256, 256, 40), (1, 8, 1024, 1024, 80), (2, 8, 64, 64, 160),
                                              (2, 8, 256, 77, 40), (1, 2, 100, 77, 64), (1, 4, 70, 130, 16),
