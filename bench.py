@@ -97,7 +97,7 @@ def cpu_baseline(sds, threads, device_decode=None):
 # value: (shape label, algorithmic bytes, launch grid in threads of that shape — what tells a family's PMC rows apart)
 # keys: (prefix the in-situ family label must START with, substring of the rocprofv3 kernel name).  The 1x1 family aggregates three
 # kernels; its PMC reference shape is a gemm_rowpanel_kernel launch, so its rows are looked up under that kernel's name.
-PMC_SHAPES = {("gemm_dma_kernel", "gemm_rowpanel_kernel"): ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320; the gemm_rowpanel_kernel launch of the gemm_dma + gemm_wide + gemm_rowpanel family, 512 panels x 512 threads)", 167976960, 262144),
+PMC_SHAPES = {("gemm_dma_kernel", "gemm_rowpanel_kernel"): ("1x1 n=32 64x64 320->320 (M=131072 N=320 K=320; the gemm_rowpanel_kernel launch of the gemm_dma + gemm_wide + gemm_p8 + gemm_rowpanel family, 512 panels x 512 threads)", 167976960, 262144),
               ("conv3x3_tile_kernel", "conv3x3_tile_kernel"): ("3x3 n=32 64x64 320->320 (M=131072 N=320 K=2880)", 169615360, 524288),
               ("attn_kernel", "attn_kernel"): ("attention B=32 H=8 N=4096 d=40", 335544320, 1048576)}
 PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
     const int M = d.N * d.Ho * d.Wo;
     const int K = d.C1;
     const int nk = K >> 6;
-    const int n_tiles = d.Cout >> 8;
+    const int n_tiles = (d.Cout + 255) >> 8;                // the last N tile may be half full (Cout % 256 == 128): clamped W rows, guarded stores
     const int nblk = n_tiles * (M >> 8);
     int bid = blockIdx.x;
     {
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
         const int row = (wave + 8 * i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
         srcx[i] = (const char*)d.x1 + ((long long)(m0 + (row >> 6) * 128 + (row & 63)) * K + chunk * 8) * 2;
-        srcw[i] = (const char*)d.w + ((long long)(n0 + (row >> 5) * 64 + (row & 31)) * K + chunk * 8) * 2;
+        int wn = n0 + (row >> 5) * 64 + (row & 31);
+        wn = wn < d.Cout ? wn : d.Cout - 1;          // columns past Cout are computed on a valid row and never stored
+        srcw[i] = (const char*)d.w + ((long long)wn * K + chunk * 8) * 2;
     }
     const long long x_h3 = (long long)64 * K * 2, w_h2 = (long long)32 * K * 2;
     // half tile h of K tile kt into buffer `buf`
@@ -130,11 +132,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
     // held through the K loop; hipcc's own counted vmcnt retires exactly these three loads, the oldest of the queue)
     // (both halves of the workgroup fetch and store the same 256 entries: no divergent branch for the wait-count pass to merge)
     const int pt = tid & 255;
-    const float par_b = d.bias ? d.bias[n0 + pt] : 0.f;
+    const int pn = n0 + pt < d.Cout ? n0 + pt : d.Cout - 1;
+    const float par_b = d.bias ? d.bias[pn] : 0.f;
     float par_c = 0.f;
     f32x2 par_mr = {0.f, 0.f};
     if (e_ln) {
-        par_c = d.ln_colsum[n0 + pt];
+        par_c = d.ln_colsum[pn];
         par_mr = *(const f32x2*)(d.ln_stats + (long long)(m0 + pt) * 2);
     }
     __builtin_amdgcn_sched_barrier(0);               // the three loads stay in front of every DMA piece
@@ -337,7 +340,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
     for (int i = tid; i < 256 * pieces; i += 512) {
         const int row = i / pieces, pc = i - row * pieces;
         if ((P8_ABL & 16) && row != 1000) continue;
-        *(u32x4*)(o + (long long)(m0 + row) * out_cols + col0 + pc * 8) = dc_stage_unswz(*(const u32x4*)(smem + row * PITCH + pc * 16), row);
+        if (col0 + pc * 8 < out_cols)
+            *(u32x4*)(o + (long long)(m0 + row) * out_cols + col0 + pc * 8) = dc_stage_unswz(*(const u32x4*)(smem + row * PITCH + pc * 16), row);
     }
 }
 
@@ -345,7 +349,7 @@ template <int EPI>
 int launch_p8(const dc_conv_desc& d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.Ho * d.Wo;
-    const int nblk = (int)(M >> 8) * (d.Cout >> 8);
+    const int nblk = (int)(M >> 8) * ((d.Cout + 255) >> 8);
     auto kern = gemm_p8_kernel<EPI>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, P8_LDS, attr_done);
@@ -367,9 +371,10 @@ int dc_gemm_p8_wanted(const dc_conv_desc& d, int epi)
     if (d.ln_stats && d.ln_parts > 0) return 0;             // the dispatcher finalizes first and comes back with pairs
     const int K = d.C1;
     const long long M = (long long)d.N * d.Ho * d.Wo;
-    if (K < 128 || (K & 63) || (M & 255) || (d.Cout & 255)) return 0;
+    if (K < 128 || (K & 63) || (M & 255) || (d.Cout & 127)) return 0;
     if (mode == 2) return 1;
-    const long long tiles = (M >> 8) * (d.Cout >> 8);
+    const long long tiles = (M >> 8) * ((d.Cout + 255) >> 8);
+    if ((d.Cout & 255) && d.Cout < 1792) return 0;          // a half-full last tile only where it is <= 1/15 of the columns' work
     return K >= min_k && tiles >= min_tiles;
 }
 

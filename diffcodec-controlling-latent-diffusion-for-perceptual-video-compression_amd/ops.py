@@ -290,7 +290,7 @@ def conv(x1, pc, *, x2=None, gn_ab=None, gn_silu=False, row_add=None, residual=N
     if lib.TIMER is not None:
         kk = pc.cin * k * k
         if k == 1 and (gn_ab is None or (not gn_silu and x2 is None and rowpanel_takes(m, ho * wo, pc.cin, pc.cout))):
-            fam = "gemm_dma_kernel + gemm_wide_kernel + gemm_rowpanel_kernel (1x1 conv / linear GEMM family)"
+            fam = "gemm_dma_kernel + gemm_wide_kernel + gemm_p8_kernel + gemm_rowpanel_kernel (1x1 conv / linear GEMM family)"
         elif k == 3 and stride == 1 and pad == 1 and (wo % 16 == 0 and ho % 4 == 0 or wo == 8 and ho % 8 == 0 and not upsample):
             fam = "conv3x3_tile_kernel (3x3 stride-1 halo-tile conv)"
         else:

@@ -496,10 +496,10 @@ def test_wide_gemm_long_k_shapes(ops, m, k, n):
     close(ops.conv(xa, pc, x2=xb).reshape(1, m, n).float().cpu(), ref)
 
 
-@pytest.mark.parametrize("m,k,n", [(8192, 640, 3584), (7168, 1344, 4096)])
+@pytest.mark.parametrize("m,k,n", [(8192, 640, 3584), (7168, 1344, 4096), (14336, 640, 1920)])
 def test_p8_gemm_shapes(ops, m, k, n):
     """Shapes the dispatcher hands to the 256 x 256 four-phase GEMM (gemm_p8.hip: no residual / statistics, whole 256 x 256 tiles,
-    >= 448 of them, K >= 640; an even and an odd number of K tiles): bias, folded LayerNorm, GEGLU, folded LayerNorm + GEGLU against
+    >= 448 of them, K >= 640; an even and an odd number of K tiles; a half-full last column tile): bias, folded LayerNorm, GEGLU, folded LayerNorm + GEGLU against
     fp32 torch on the same bf16 operands.  Each launch twice (the DMA / barrier protocol must give the same bits), and the first 256
     rows against a 256-row launch of the same operator, which another kernel of the family takes: the kernels accumulate in the
     same order with the same epilogue arithmetic, so the bits must agree."""

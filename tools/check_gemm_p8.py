@@ -16,7 +16,7 @@ if os.environ.get("DC_LIB_PATH"):
 g = torch.Generator().manual_seed(0)
 out = {}
 for (m, cin, cout, kind) in [(8192, 1280, 3840, "l"), (8192, 1280, 10240, "lg"), (32768, 640, 5120, "lg"), (8192, 1280, 1280, "p"), (2048, 1280, 10240, "lg"),
-                             (8192, 1280, 1280, "r"), (512, 128, 256, "p"), (256, 192, 512, "g"), (1024, 320, 2560, "lg"), (768, 448, 768, "l"), (32768, 640, 1920, "l")]:
+                             (8192, 1280, 1280, "r"), (512, 128, 256, "p"), (256, 192, 512, "g"), (1024, 320, 2560, "lg"), (768, 448, 768, "l"), (32768, 640, 1920, "l"), (1024, 256, 640, "lg"), (512, 128, 384, "p"), (14336, 640, 1920, "g")]:
     x = torch.randn(1, m, cin, generator=g).to("cuda", torch.bfloat16)
     w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
     ln = (1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g), 1e-5) if "l" in kind else None

@@ -22,6 +22,16 @@ for (cout, geglu) in [(960, False), (2560, True)]:
         yl = ops.linear(xr, pcl, ln_stats=mr)
     torch.cuda.synchronize()
     print(f"shape rowpanel M={n*4096} K=320 N={cout} geglu={int(geglu)}: algorithmic bytes = {xr.numel()*2 + pcl.w.numel()*2 + yl.numel()*2}")
+# the wide GEGLU projections of the 32x32 and 16x16 transformers on the 256 x 256 four-phase kernel (gemm_p8.hip)
+for (hw, cin, cout) in [(1024, 640, 5120), (256, 1280, 10240)]:
+    xp = torch.randn(1, n * hw, cin, generator=g).to("cuda", torch.bfloat16)
+    mrp = ops.ln_finalize(ops.row_stats(xp), cin, 1e-5)
+    lnp = (1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g), 1e-5)
+    pcp = ops.PackedConv(torch.randn(cout, cin, generator=g) / math.sqrt(cin), torch.zeros(cout), "cuda", geglu=True, ln=lnp)
+    for _ in range(5):
+        yp = ops.linear(xp, pcp, ln_stats=mrp)
+    torch.cuda.synchronize()
+    print(f"shape p8 M={n*hw} K={cin} N={cout} geglu=1: algorithmic bytes = {xp.numel()*2 + pcp.w.numel()*2 + yp.numel()*2}")
 # flash attention, d = 40, 64x64 tokens (the third family by time)
 q = torch.randn(n, 4096, 960, generator=g).to("cuda", torch.bfloat16)
 for _ in range(3):
