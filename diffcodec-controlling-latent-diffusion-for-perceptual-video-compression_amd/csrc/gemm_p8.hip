@@ -70,7 +70,7 @@ __device__ __forceinline__ void p8_wait_lgkm()
 
 // EPI: 1 bias, 3 folded LayerNorm + bias, 4 GEGLU, 5 folded LayerNorm + GEGLU (the numbering of gemm_dma.hip)
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
+__global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d, const int gm)
 {
     constexpr bool e_geglu = EPI >= 4, e_ln = EPI == 3 || EPI == 5;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,7 +90,21 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d)
         const int xq = nblk >> 3, xr = nblk & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;
     }
-    const int tile_n = bid % n_tiles, tile_m = bid / n_tiles;
+    // Tile order inside an XCD's contiguous range: groups of `gm` row tiles, the row tile the fastest index inside a group, so the 32
+    // workgroups an XCD runs together form a gm x (32 / gm) block of tiles and share gm X panels + 32 / gm W panels in its L2
+    // (column-fastest order: 1 + 32 panels — 7.4x the algorithmic bytes from beyond L2 at N = 10240).
+    int tile_m, tile_n;
+    if (gm > 0) {
+        const int per_group = gm * n_tiles;
+        const int group = bid / per_group, in_group = bid - group * per_group;
+        const int first_m = group * gm;
+        const int rows = min(gm, (M >> 8) - first_m);
+        tile_m = first_m + in_group % rows;
+        tile_n = in_group / rows;
+    } else {
+        tile_n = bid % n_tiles;
+        tile_m = bid / n_tiles;
+    }
     const int m0 = tile_m << 8, n0 = tile_n << 8;
 
     // ---- DMA sources.  Piece j of a half tile = its rows [8j, 8j+8); this wave issues pieces `wave` and `wave + 8`; lane s ->
@@ -353,7 +367,8 @@ int launch_p8(const dc_conv_desc& d, hipStream_t st)
     auto kern = gemm_p8_kernel<EPI>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, P8_LDS, attr_done);
-    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), P8_LDS, st, d);
+    static const int gm = DC_KNOB("DC_P8_GM", 8);           // developer A/B knob: 0 = column-fastest order
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), P8_LDS, st, d, gm);
     return dc_launch_status();
 }
 

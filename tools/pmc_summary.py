@@ -7,7 +7,7 @@ for arg in sys.argv[1:]:
     for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"] + " grid=" + r["Grid_Size"]
-            if not any(t in k for t in ("conv3x3_tile", "gemm_dma", "gemm_wide", "gemm_rowpanel", "conv3x3_f32_mfma", "attn_kernel", "gn_apply", "gn_stats", "igemm_kernel")):
+            if not any(t in k for t in ("conv3x3_tile", "gemm_dma", "gemm_wide", "gemm_p8", "gemm_rowpanel", "conv3x3_f32_mfma", "attn_kernel", "gn_apply", "gn_stats", "igemm_kernel")):
                 continue
             d = acc.setdefault(k, {})
             v = d.setdefault(r["Counter_Name"], [0.0, 0])
