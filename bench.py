@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--dual-stream", type=int, default=1, help="1: ControlNet and UNet down path on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the post-timing legs (profiling runs)")
-    ap.add_argument("--c3-batch", type=int, default=22, help="units per pipe call of the strong-scaling C3 pass")
+    ap.add_argument("--c3-batch", type=int, default=44, help="units per pipe call of the strong-scaling C3 pass")
     ap.add_argument("--shapes-out", default=None, help="write the in-situ per-shape launch table of the roofline leg to this file")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
