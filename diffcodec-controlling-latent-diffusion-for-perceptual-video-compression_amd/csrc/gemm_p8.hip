@@ -36,9 +36,6 @@ typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-#ifndef P8_WAITS
-#define P8_WAITS 0                                  // developer A/B switch: 0 = one counted wait per K tile (all of tile t+1 by the end of tile t)
-#endif
 #ifndef P8_ABL
 #define P8_ABL 0                                    // developer timing ablations (wrong results): 1 no DMA in the K loop, 2 no fragment reads, 4 no MFMAs, 8 no barriers, 16 no output stores
 #endif
@@ -109,28 +106,32 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d, c
 
     // ---- DMA sources.  Piece j of a half tile = its rows [8j, 8j+8); this wave issues pieces `wave` and `wave + 8`; lane s ->
     //      row 8j + (s >> 3), LDS slot s & 7, which holds source chunk (s & 7) ^ (row & 7).
-    const char* srcx[2];                             // H0 (H3 = + 64 rows)
-    const char* srcw[2];                             // H1 (H2 = + 32 rows)
+    //      Sources are a workgroup-uniform base (SGPRs: tile origin + K offset of the half tile) plus a 32-bit per-lane offset, so a
+    //      piece costs no vector address arithmetic.
+    uint32_t offx[2], offw[2];                       // H0 / H1 (H3 = + 64 rows, H2 = + 32 rows: in the uniform base)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave + 8 * i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ (row & 7);
-        srcx[i] = (const char*)d.x1 + ((long long)(m0 + (row >> 6) * 128 + (row & 63)) * K + chunk * 8) * 2;
+        offx[i] = (uint32_t)(((row >> 6) * 128 + (row & 63)) * K + chunk * 8) * 2u;
         int wn = n0 + (row >> 5) * 64 + (row & 31);
-        wn = wn < d.Cout ? wn : d.Cout - 1;          // columns past Cout are computed on a valid row and never stored
-        srcw[i] = (const char*)d.w + ((long long)wn * K + chunk * 8) * 2;
+        // columns past Cout (whole 64-column wave slices of a half-full last tile) are computed on valid rows and never stored: row
+        // Cout - 33 for H1, so that H2 (the same offsets + 32 rows) ends on row Cout - 1
+        wn = wn < d.Cout ? wn : d.Cout - 33;
+        offw[i] = (uint32_t)((wn - n0) * K + chunk * 8) * 2u;
     }
+    const char* const bx = (const char*)d.x1 + (long long)m0 * K * 2;
+    const char* const bw = (const char*)d.w + (long long)n0 * K * 2;
     const long long x_h3 = (long long)64 * K * 2, w_h2 = (long long)32 * K * 2;
     // half tile h of K tile kt into buffer `buf`
     auto issue_half = [&](int h, int kt, int buf) {
         char* base = smem + buf * P8_BUF + h * P8_HALF + wave * 1024;
-        const long long koff = (long long)kt * 128 + (h == 3 ? x_h3 : (h == 2 ? w_h2 : 0));
         const bool is_x = h == 0 || h == 3;
+        const char* sb = (is_x ? bx : bw) + (h == 3 ? x_h3 : (h == 2 ? w_h2 : 0));
+        const uint32_t ko = (uint32_t)kt * 128u;     // the K offset rides in the 32-bit lane offset (one v_add_u32 per piece), the rest in SGPRs
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* p = (is_x ? srcx[i] : srcw[i]) + koff;
-            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + i * 8192), 16, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(sb + (size_t)(uint32_t)((is_x ? offx[i] : offw[i]) + ko)), (lptr_t)(base + i * 8192), 16, 0, 0);
     };
 
     // ---- fragment read bases (byte offsets into a K tile's buffer; + 2048 per 16-row block, + half-tile offset)
@@ -173,13 +174,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d, c
     *(float*)(smem + P8_PAR_BIAS + pt * 4) = par_b;
     *(float*)(smem + P8_PAR_CS + pt * 4) = par_c;
     *(f32x2*)(smem + P8_PAR_LN + pt * 8) = par_mr;
-#if P8_WAITS
-    if (nk > 1) p8_wait_vm_lgkm<10>();               // H0 and H1 of tile 0
-    else p8_wait_vm_lgkm<4>();
-#else
     if (nk > 1) p8_wait_vm_lgkm<6>();
     else p8_wait_vm_lgkm<0>();
-#endif
     p8_barrier();                                    // tile 0 visible to every wave
     if (grp == 1) p8_barrier();                      // group 1 runs one barrier behind
 
@@ -217,76 +213,39 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const dc_conv_desc d, c
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // counted wait for `n` pieces still in flight (n = 10 in the steady state; the last two K tiles issue fewer)
-    auto wait_pieces = [&](int n, bool lgkm) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (lgkm) {
-            switch (n) {
-                case 10: asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-            }
-        } else {
-            switch (n) {
-                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
-        }
-    };
-    // One K tile.  STEADY: tiles t+1 and t+2 exist (no conditions in the body).  Every R phase ends with the wait for the half
-    // tile(s) the NEXT phase reads: 5 half tiles (10 pieces of this wave) stay in flight across it.
+    // One K tile.  STEADY: tiles t+1 and t+2 exist (no conditions in the body).
     auto k_tile = [&](auto par_c, auto steady_c, int t) {
         constexpr int P = decltype(par_c)::value;
         constexpr bool STEADY = decltype(steady_c)::value;
         const char* buf = smem + P * P8_BUF;
         const bool n1 = STEADY || t + 1 < nk, n2 = STEADY || t + 2 < nk;
-        // phase 1: X rows 0-63, W cols 0-31; then H2(t) must have landed
+        // phase 1: X rows 0-63, W cols 0-31
         read_w(wb0, buf, 1 * P8_HALF);
         __builtin_amdgcn_sched_barrier(0);
         read_x(buf, 0);
         if (n1 && !(P8_ABL & 1)) issue_half(3, t + 1, P ^ 1);
-#if P8_WAITS
-        if (STEADY) p8_wait_vm_lgkm<10>();
-        else wait_pieces(n1 ? 10 : 2, true);
-#else
         p8_wait_lgkm();
-#endif
         p8_barrier();
         quadrant(I0{}, I0{}, wb0);
         p8_barrier();
-        // phase 2: W cols 32-63; then H3(t)
+        // phase 2: W cols 32-63
         read_w(wb1, buf, 2 * P8_HALF);
         if (n2 && !(P8_ABL & 1)) issue_half(0, t + 2, P);
-#if P8_WAITS
-        if (STEADY) p8_wait_vm_lgkm<10>();
-        else wait_pieces(n2 ? 10 : (n1 ? 8 : 0), true);
-#else
         p8_wait_lgkm();
-#endif
         p8_barrier();
         quadrant(I1{}, I0{}, wb1);
         p8_barrier();
-        // phase 3: X rows 64-127; the next phase reads nothing
+        // phase 3: X rows 64-127
         read_x(buf, 3 * P8_HALF);
         if (n2 && !(P8_ABL & 1)) issue_half(1, t + 2, P);
         p8_wait_lgkm();
         p8_barrier();
         quadrant(I1{}, I1{}, wb1);
         p8_barrier();
-        // phase 4: no reads (W cols 0-31 are still in registers); then H0 and H1 of tile t+1
+        // phase 4: no reads (W cols 0-31 are still in registers); all of tile t+1 must have landed before the next phase reads it
         if (n2 && !(P8_ABL & 1)) issue_half(2, t + 2, P);
-#if P8_WAITS
-        if (STEADY) p8_wait_vm_lgkm<10>();
-        else wait_pieces(n2 ? 10 : (n1 ? 4 : 0), true);
-#else
         if (n2) p8_wait_vm_lgkm<6>();
         else p8_wait_vm_lgkm<0>();
-#endif
         p8_barrier();
         quadrant(I0{}, I1{}, wb0);
         p8_barrier();
@@ -364,10 +323,10 @@ int launch_p8(const dc_conv_desc& d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.Ho * d.Wo;
     const int nblk = (int)(M >> 8) * ((d.Cout + 255) >> 8);
+    static const int gm = DC_KNOB("DC_P8_GM", 8);           // developer A/B knob: 0 = column-fastest order
     auto kern = gemm_p8_kernel<EPI>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, P8_LDS, attr_done);
-    static const int gm = DC_KNOB("DC_P8_GM", 8);           // developer A/B knob: 0 = column-fastest order
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), P8_LDS, st, d, gm);
     return dc_launch_status();
 }

@@ -16,7 +16,7 @@ if os.environ.get("DC_LIB_PATH"):
 g = torch.Generator().manual_seed(0)
 out = {}
 for (m, cin, cout, kind) in [(8192, 1280, 3840, "l"), (8192, 1280, 10240, "lg"), (32768, 640, 5120, "lg"), (8192, 1280, 1280, "p"), (2048, 1280, 10240, "lg"),
-                             (8192, 1280, 1280, "r"), (512, 128, 256, "p"), (256, 192, 512, "g"), (1024, 320, 2560, "lg"), (768, 448, 768, "l"), (32768, 640, 1920, "l"), (1024, 256, 640, "lg"), (512, 128, 384, "p"), (14336, 640, 1920, "g")]:
+                             (8192, 1280, 1280, "r"), (512, 128, 256, "p"), (256, 192, 512, "g"), (1024, 320, 2560, "lg"), (768, 448, 768, "l"), (32768, 640, 1920, "l"), (1024, 256, 640, "lg"), (512, 128, 384, "p"), (14336, 640, 1920, "g"), (8192, 256, 4224, "lg"), (16384, 128, 2560, "g"), (9984, 384, 3584, "g")]:
     x = torch.randn(1, m, cin, generator=g).to("cuda", torch.bfloat16)
     w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
     ln = (1 + 0.1 * torch.randn(cin, generator=g), 0.1 * torch.randn(cin, generator=g), 1e-5) if "l" in kind else None
@@ -25,6 +25,9 @@ for (m, cin, cout, kind) in [(8192, 1280, 3840, "l"), (8192, 1280, 10240, "lg"),
     mr = ops.ln_finalize(ops.row_stats(x), cin, 1e-5) if ln is not None else None
     y = ops.linear(x, pc, residual=res, ln_stats=mr, out_scale=0.75 if kind == "r" else 1.0)
     torch.cuda.synchronize()
+    for _ in range(3):
+        y2 = ops.linear(x, pc, residual=res, ln_stats=mr, out_scale=0.75 if kind == "r" else 1.0)
+        assert torch.equal(y, y2), f"launch-to-launch difference at M={m} K={cin} N={cout} {kind}"
     out[f"M={m} K={cin} N={cout} {kind}"] = y.cpu()
 torch.save(out, sys.argv[2])
 print("saved", len(out), "outputs to", sys.argv[2])
