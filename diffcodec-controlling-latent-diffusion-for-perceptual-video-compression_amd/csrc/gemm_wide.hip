@@ -80,10 +80,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
 
     // ---- per-lane DMA sources: piece g = wave + 8 i covers stage rows [8g, 8g+8); lane s -> row 8g + (s>>3), LDS slot s&7,
     //      which must hold source chunk (s&7) ^ (row&7)
-    const char* src1[PMAX];
-    const char* src2[PMAX];
+    //      Addresses are a workgroup-uniform base (SGPRs: tile origin of the operand) + a 32-bit per-lane offset that also carries the K
+    //      offset of the stage (one v_add_u32 per piece; a 64-bit per-lane pointer costs two registers and a 64-bit vector add per piece,
+    //      issued while the partner group's MFMAs hold the vector port — gemm_p8.hip measured 2-3 % for the same change).
+    uint32_t off1[PMAX], off2[PMAX];
     const int c1_steps = d.C1 >> 6;
     const int my_pieces = (NP - wave + 7) / 8;        // wave-uniform: PMAX or PMAX - 1
+    const char* const bx1 = (const char*)d.x1 + (long long)m0 * d.C1 * 2;
+    const char* const bx2 = d.x2 ? (const char*)d.x2 + (long long)m0 * d.C2 * 2 : nullptr;
+    const char* const bw = (const char*)d.w + (long long)n0 * K * 2;
 #pragma unroll
     for (int i = 0; i < PMAX; ++i) {
         int g = wave + 8 * i;
@@ -93,24 +98,26 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
         if (row < BM) {
             int m = m0 + row;
             m = m < M ? m : M - 1;                    // clamp: rows past M are computed and discarded
-            src1[i] = (const char*)d.x1 + ((long long)m * d.C1 + chunk * 8) * 2;
-            src2[i] = d.x2 ? (const char*)d.x2 + ((long long)m * d.C2 + chunk * 8) * 2 : nullptr;
+            off1[i] = (uint32_t)((m - m0) * d.C1 + chunk * 8) * 2u;
+            off2[i] = (uint32_t)((m - m0) * d.C2 + chunk * 8) * 2u;
         } else {
             int n = n0 + row - BM;
             n = n < d.Cout ? n : d.Cout - 1;
-            src1[i] = (const char*)d.w + ((long long)n * K + chunk * 8) * 2;
-            src2[i] = nullptr;
+            off1[i] = (uint32_t)((n - n0) * K + chunk * 8) * 2u;
+            off2[i] = 0;
         }
     }
     auto issue_stage = [&](int kt, int slot) {
         char* base = smem + slot * STAGE;
         const bool second = kt >= c1_steps;
+        const uint32_t ko1 = (uint32_t)kt * 128u, ko2 = (uint32_t)(kt - c1_steps) * 128u;
 #pragma unroll
         for (int i = 0; i < PMAX; ++i) {
             if (i == PMAX - 1 && my_pieces < PMAX) break;                        // wave-uniform
             const int g = wave + 8 * i;
             const bool is_a = g * 8 < BM;                                        // wave-uniform
-            const char* p = (second && is_a) ? src2[i] + (long long)(kt - c1_steps) * 128 : src1[i] + (long long)kt * 128;
+            const char* p = is_a ? ((second ? bx2 : bx1) + (size_t)(uint32_t)((second ? off2[i] : off1[i]) + (second ? ko2 : ko1)))
+                                 : (bw + (size_t)(uint32_t)(off1[i] + ko1));
             __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(base + g * 1024), 16, 0, 0);
         }
     };
