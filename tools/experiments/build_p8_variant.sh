@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 name=$1; shift
 PKG=diffcodec-controlling-latent-diffusion-for-perceptual-video-compression_amd
+mkdir -p tools/ab/p8
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-result -DDC_DEV_KNOBS "$@" -c $PKG/csrc/gemm_p8.hip -o tools/ab/p8/gemm_p8_$name.o
 objs=$(ls tools/ab/obj/*.o | grep -v gemm_p8.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ab/libdc_p8_$name.so $objs tools/ab/p8/gemm_p8_$name.o
