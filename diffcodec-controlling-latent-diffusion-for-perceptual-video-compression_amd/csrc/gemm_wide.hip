@@ -40,8 +40,12 @@ __device__ __forceinline__ void wg_barrier()
     asm volatile("" ::: "memory");
 }
 
-// EPI as in gemm_dma.hip: 1 bias, 2 bias + scale + residual, 3 folded LayerNorm + bias, 4 GEGLU, 5 folded LayerNorm + GEGLU
-template <int TN, int EPI>
+// EPI as in gemm_dma.hip: 1 bias, 2 bias + scale + residual, 3 folded LayerNorm + bias, 4 GEGLU, 5 folded LayerNorm + GEGLU.
+// ST (EPI 1 / 2): bit 0 = LayerNorm row statistics of the output requested (`stats_out`), bit 1 = GroupNorm partials (`gn_part_out`).
+// A compile-time choice: the sums cost 24 vector operations per 16 x 16 block (480 per wave and tile), most launches of this kernel
+// request one kind or none (the feed-forward down-projection), and run-time branches around them inside the unrolled epilogue make
+// hipcc spill thousands of dwords.
+template <int TN, int EPI, int ST>
 __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
 {
     constexpr int TM = 4, NST = 3;
@@ -60,8 +64,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
     const int wm = wave & 1, wn = (wave >> 1) & 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int wrow = grp * 128 + wm * TM * 16;        // first row of this wave's tiles inside the workgroup tile
-    const bool e_stats = (EPI == 1 || EPI == 2) && d.stats_out != nullptr;
-    const bool e_gnpart = (EPI == 1 || EPI == 2) && d.gn_part_out != nullptr;
+    static_assert(ST == 0 || EPI == 1 || EPI == 2, "statistics ride on the bias / residual epilogues only");
+    constexpr bool e_stats = (ST & 1) != 0, e_gnpart = (ST & 2) != 0;
 
     const int HoWo = d.Ho * d.Wo;
     const int M = d.N * HoWo;
@@ -259,10 +263,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)v[r];
                 *(bf16x4*)(smem + row * PITCH + ((nl * 2) ^ dc_stage_swz(row))) = pk;
-                if (EPI == 1 || EPI == 2) {
+                if (e_stats) {                        // compile-time
                     const float cm = nb < d.Cout ? 1.f : 0.f;
                     st1 += cm * ((v[0] + v[1]) + (v[2] + v[3]));
                     st2 += cm * ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+                }
+                if (e_gnpart) {
                     gs[tn] += rowmask * v;
                     gq[tn] += rowmask * (v * v);
                 }
@@ -300,18 +306,33 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_kernel(const dc_conv_desc d)
     }
 }
 
-template <int TN, int EPI>
-int launch_wide(const dc_conv_desc& d, hipStream_t st)
+template <int TN, int EPI, int ST>
+int launch_wide_st(const dc_conv_desc& d, hipStream_t st)
 {
     constexpr int BN = 2 * TN * 16;
     const int M = d.N * d.Ho * d.Wo;
     const int nblk = dc_cdiv(M, 256) * dc_cdiv(d.Cout, BN);
     const size_t lds = (size_t)3 * (256 + BN) * 128;
-    auto kern = gemm_wide_kernel<TN, EPI>;
+    auto kern = gemm_wide_kernel<TN, EPI, ST>;
     static std::atomic<unsigned long long> attr_done{0};
     dc_set_max_dyn_lds((const void*)kern, (int)lds, attr_done);
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, d);
     return dc_launch_status();
+}
+
+template <int TN, int EPI>
+int launch_wide(const dc_conv_desc& d, hipStream_t st)
+{
+    if constexpr (EPI == 1 || EPI == 2) {
+        switch ((d.stats_out ? 1 : 0) | (d.gn_part_out ? 2 : 0)) {
+            case 1: return launch_wide_st<TN, EPI, 1>(d, st);
+            case 2: return launch_wide_st<TN, EPI, 2>(d, st);
+            case 3: return launch_wide_st<TN, EPI, 3>(d, st);
+            default: return launch_wide_st<TN, EPI, 0>(d, st);
+        }
+    } else {
+        return launch_wide_st<TN, EPI, 0>(d, st);
+    }
 }
 
 }  // namespace
